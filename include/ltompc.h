@@ -1,0 +1,150 @@
+/*
+ * ltompc.h — C ABI of the MI355X-native receding-horizon NLP solver (libltompc.so).
+ *
+ * Drop-in boundary for the one hot path of bruno-maruszczak/lap-time-optimization:
+ *     u0 = controller.mpc.make_step(x0)                      reference src/mpc.py:142
+ * i.e. do_mpc's MPC object as configured by src/mpc/controller.py:9-103 over the model of
+ * src/mpc/model.py:130-185 and the look-up tables of src/path.py:96-101, src/mpc/track.py:30-42.
+ * The reference has no FFI of its own (it is pure Python over do_mpc/CasADi/IPOPT); the entry points
+ * below are what a ctypes binding for that path binds (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - all floating point is IEEE double; all arrays are plain C arrays, row-major, no torch types;
+ *   - state  x = [s, n, mu, vx, vy, r, steering_angle, throttle]          (model.py:138-147)
+ *     input  u = [steering_angle_change, throttle_change]                  (model.py:149-150)
+ *   - a handle owns B independent MPC instances ("batch"); instance b is row b of every array;
+ *   - every function returns 0 on success, <0 on a usage / HIP error (ltompc_last_error() has the text).
+ *     Solver non-convergence is NOT an error (the reference returns IPOPT's last iterate silently,
+ *     SURVEY.md §8b): it is reported per instance in `status`.
+ *   - a handle is not thread-safe; distinct handles are independent.  Calls are synchronous unless the
+ *     name ends in _async (those only enqueue on the handle's stream).
+ */
+#ifndef LTOMPC_H
+#define LTOMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTOMPC_NX 8
+#define LTOMPC_NU 2
+#define LTOMPC_NO_BOUND 1.0e30 /* |bound| >= this means "not set" (controller.py:78 `not_set`) */
+#define LTOMPC_TABLE_ROWS 6    /* s_kappa, kappa, s_arc, n_left, n_right, v_ref */
+
+/* per-instance solver status written by make_step */
+#define LTOMPC_STATUS_SOLVED 0          /* scaled KKT error <= tol                                */
+#define LTOMPC_STATUS_ACCEPTABLE 1      /* <= acceptable_tol for acceptable_iter iterations       */
+#define LTOMPC_STATUS_MAX_ITER 2        /* iteration budget exhausted, last iterate returned      */
+#define LTOMPC_STATUS_NUMERICAL 3       /* non-finite value / regularisation overflow             */
+#define LTOMPC_STATUS_STALLED 4         /* no progress (locally infeasible problem): IPOPT would report
+                                           'restoration failed / local infeasibility'             */
+
+/* Vehicle + objective + bounds.  Defaults (ltompc_default_params) are the values the reference
+ * actually uses, including its quirks: D_f = D_r = 1.0 because model.py:42-64
+ * never reads them; car length in the boundary constraint is length_f + length_r (model.py:71). */
+typedef struct ltompc_params {
+  /* model.py:42-64, constructor defaults :16-29 */
+  double mass, inertia_z, length_f, length_r, width;
+  double B_f, C_f, D_f, B_r, C_r, D_r;
+  double C_m, Cr_0, Cr_2, gravity;
+  /* controller.py:29,52-53: lterm = q_n n^2 + q_mu mu^2 + q_vy vy^2 + q_v (vx - vref_scale*v_ref(s))^2
+   *                                 + q_B (atan(vy/vx) - atan(delta*l_r/(l_f+l_r)))^2 ; mterm = first three.
+   * controller.py:40-41 + mpc.py:104: rterm = sum_i r_du[i] * (u_k[i] - u_{k-1}[i])^2                  */
+  double q_n, q_mu, q_vy, q_v, vref_scale, q_B;
+  double r_du[LTOMPC_NU];
+  /* controller.py:79-103 (LTOMPC_NO_BOUND where the reference sets nothing) */
+  double x_lb[LTOMPC_NX], x_ub[LTOMPC_NX];
+  double u_lb[LTOMPC_NU], u_ub[LTOMPC_NU];
+} ltompc_params;
+
+/* NLP transcription + interior-point options.  Defaults follow do_mpc 4.6.5 / IPOPT 3.14 defaults
+ * as listed in SURVEY.md App. B (t_step, Radau-IIA deg 2, tol 1e-8, mu_init 0.1, monotone mu, ...). */
+typedef struct ltompc_options {
+  double t_step;          /* controller.py:9            0.1  */
+  double tol;             /* ipopt tol                  1e-8 */
+  double acceptable_tol;  /* ipopt acceptable_tol       1e-6 */
+  double mu_init;         /* ipopt mu_init              0.1  */
+  double mu_min;          /* tol/10                     1e-9 */
+  double kappa_eps;       /* barrier_tol_factor         10   */
+  double kappa_mu;        /* mu_linear_decrease_factor  0.2  */
+  double theta_mu;        /* mu_superlinear_decrease_power 1.5 */
+  double tau_min;         /* fraction-to-boundary       0.99 */
+  double bound_push;      /* slack initialisation       1e-2 */
+  double s_max;           /* dual-residual scaling cap  100  */
+  double delta_w_first;   /* first Hessian regularisation 1e-4 */
+  /* Smoothing of the reference NLP's kinks (|mu| in model.py:77-78, table knots): eps = max(smooth_eps_min,
+   * smooth_scale * mu_barrier) in rad resp. metres; both 0 = the exact non-smooth functions. */
+  double smooth_eps_min;  /* 1e-4 */
+  double smooth_scale;    /* 1.0  */
+  int max_iter;           /* controller.py:18 says 1000 */
+  int acceptable_iter;    /* ipopt acceptable_iter      15   */
+  int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
+  int stall_iter;         /* stop (status STALLED) after this many consecutive steps with alpha <= 1e-3; 0 = off */
+} ltompc_options;
+
+typedef struct ltompc_solver* ltompc_handle;
+
+void ltompc_default_params(ltompc_params* p);
+void ltompc_default_options(ltompc_options* o);
+const char* ltompc_last_error(void);
+const char* ltompc_version(void);
+
+/* Replaces Controller(model, control_costs, n_horizon, t_step) + mpc.setup()   (controller.py:9-34).
+ * tables: LTOMPC_TABLE_ROWS x n_table doubles, row-major (rows as named above; path.py:96-101,
+ *         mpc/track.py:30-42).  n_horizon = N; batch = number of independent MPC instances;
+ * device: HIP device ordinal.  Allocates every device workspace; no allocation happens per call later. */
+int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables,
+                  int n_table, int n_horizon, int batch, int device, ltompc_handle* out);
+int ltompc_destroy(ltompc_handle h);
+
+/* Run on this HIP stream (hipStream_t as void*); NULL = the handle's own stream. */
+int ltompc_set_stream(ltompc_handle h, void* hip_stream);
+
+/* Replaces `mpc.x0 = x0; mpc.set_initial_guess()`  (mpc.py:117-118): every state slot of instance b := x0[b],
+ * every input := 0, u_prev := 0, multipliers reset.  x0: batch x 8 (host). */
+int ltompc_set_initial_guess(ltompc_handle h, const double* x0);
+
+/* Replaces `u0 = mpc.make_step(x0)`  (mpc.py:142).  Solves the B NLPs warm-started from the handle's
+ * previous solution (un-shifted, like do_mpc), u_prev := last returned u0.
+ *   x0: batch x 8 (host, in)      u0: batch x 2 (host, out)
+ *   status, iters: batch ints (host, out; may be NULL). */
+int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status, int* iters);
+
+/* Same, device pointers, enqueue only (x0_dev: batch x 8, u0_dev: batch x 2, row-major, on the handle's
+ * device).  Converged instances idle; the call enqueues `max_iter` iterations unless ltompc_make_step_dev
+ * finds all instances finished earlier (it polls a device counter every `poll_every` iterations). */
+int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev);
+
+/* Predicted trajectories of the last solve (do_mpc: mpc.opt_x_num['_x', k, 0, -1], ['_u', k, 0]).
+ *   X: batch x (N+1) x 8, U: batch x N x 2 (host, out; either may be NULL). */
+int ltompc_get_prediction(ltompc_handle h, double* X, double* U);
+
+/* Per-instance results of the last solve (host, out; any may be NULL):
+ *   status, iters: ints;  kkt_error: scaled KKT error E_0;  objective: NLP objective J;  mu: last barrier. */
+int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error, double* objective,
+                     double* mu);
+
+/* Full primal/dual iterate of the last solve, for KKT checks (host, out; any may be NULL):
+ *   X: B x (N+1) x 8, C: B x N x 8 (first Radau point), U: B x N x 2,
+ *   L1, L2: B x N x 8 (collocation multipliers).                                   */
+int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double* L1, double* L2);
+
+/* Plant step: replaces sim.make_step(u0) (src/mpc/simulator.py:18-20, mpc.py:143): integrates the model ODE
+ * over t_step under zero-order-hold u with n_sub classical RK4 sub-steps.  x, x_next: batch x 8; u: batch x 2
+ * (host).  _dev variant: device pointers, enqueue only. */
+int ltompc_plant_step(ltompc_handle h, const double* x, const double* u, int n_sub, double* x_next);
+int ltompc_plant_step_dev(ltompc_handle h, const double* x_dev, const double* u_dev, int n_sub,
+                          double* x_next_dev);
+
+/* Slip angles and Pacejka lateral forces (model.py:101-114; called per tick at mpc.py:148-150).
+ * x: batch x 8 -> alpha: batch x 2 (front, rear), Fy: batch x 2.  Host pointers, computed on the device. */
+int ltompc_slip_forces(ltompc_handle h, const double* x, int batch, double* alpha, double* Fy);
+
+/* Timing of the last make_step: device time in ms per kernel class (eval, riccati, expand, linesearch, pick)
+ * measured with HIP events on the handle's stream; launches = kernel launches issued. */
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel5, int* launches, int* ip_iterations);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LTOMPC_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of the CPU oracle (oracle/ltompc_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package never does (it fails loudly when the HIP library is missing instead of falling back to this).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libltompc_oracle.so")
+NX, NU = 8, 2
+
+
+class Params(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "mass", "inertia_z", "length_f", "length_r", "width", "B_f", "C_f", "D_f", "B_r", "C_r", "D_r",
+        "C_m", "Cr_0", "Cr_2", "gravity", "q_n", "q_mu", "q_vy", "q_v", "vref_scale", "q_B")] + [
+        ("r_du", C.c_double * 2), ("x_lb", C.c_double * 8), ("x_ub", C.c_double * 8),
+        ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2)]
+
+
+class Options(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
+        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale")] + [
+        ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "ltompc_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def default_params() -> Params:
+    p = Params()
+    lib().oracle_default_params(C.byref(p))
+    return p
+
+
+def default_options() -> Options:
+    o = Options()
+    lib().oracle_default_options(C.byref(o))
+    return o
+
+
+class Oracle:
+    """CPU restatement of the make_step path over one set of tables."""
+
+    def __init__(self, tables_packed: np.ndarray, params: Params | None = None, options: Options | None = None):
+        self.tab = np.ascontiguousarray(tables_packed, dtype=np.float64)
+        assert self.tab.ndim == 2 and self.tab.shape[0] == 6
+        self.nt = self.tab.shape[1]
+        self.p = params or default_params()
+        self.o = options or default_options()
+
+    # ---- model pieces -------------------------------------------------------------
+    def rhs(self, x, u):
+        x = np.ascontiguousarray(x, float); u = np.ascontiguousarray(u, float)
+        f = np.zeros(8)
+        lib().oracle_rhs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(u), _p(f))
+        return f
+
+    def rhs_derivs(self, x, lam):
+        x = np.ascontiguousarray(x, float); lam = np.ascontiguousarray(lam, float)
+        f, fx, H = np.zeros(8), np.zeros((8, 8)), np.zeros((8, 8))
+        lib().oracle_rhs_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(lam), _p(f), _p(fx), _p(H))
+        return f, fx, H
+
+    def cost_derivs(self, x, terminal=False):
+        x = np.ascontiguousarray(x, float)
+        v = C.c_double(); g, H = np.zeros(8), np.zeros((8, 8))
+        lib().oracle_cost_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), int(terminal), C.byref(v), _p(g), _p(H))
+        return v.value, g, H
+
+    def cons_derivs(self, x):
+        x = np.ascontiguousarray(x, float)
+        v, g, H = np.zeros(3), np.zeros((3, 8)), np.zeros((3, 8, 8))
+        lib().oracle_cons_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(v), _p(g), _p(H))
+        return v, g, H
+
+    def slip_forces(self, x):
+        x = np.ascontiguousarray(np.atleast_2d(x), float)
+        a, F = np.zeros((x.shape[0], 2)), np.zeros((x.shape[0], 2))
+        lib().oracle_slip_forces(C.byref(self.p), _p(x), x.shape[0], _p(a), _p(F))
+        return a, F
+
+    def plant_step(self, x, u, dt=None, n_sub=400):
+        x = np.ascontiguousarray(np.atleast_2d(x), float); u = np.ascontiguousarray(np.atleast_2d(u), float)
+        xn = np.zeros_like(x)
+        lib().oracle_plant_step(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(u), x.shape[0],
+                                C.c_double(dt if dt is not None else self.o.t_step), int(n_sub), _p(xn))
+        return xn
+
+    # ---- NLP solve ----------------------------------------------------------------
+    def solve(self, x0, N, uprev=None, warm=None, nthreads=0):
+        """x0: (B,8).  warm: dict(X,C,U,L1,L2) of a previous solve or None (do_mpc set_initial_guess).
+        Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail)."""
+        x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
+        B = x0.shape[0]
+        uprev = np.zeros((B, 2)) if uprev is None else np.ascontiguousarray(np.atleast_2d(uprev), float)
+        if warm is None:
+            X, Cc, U = np.zeros((B, N + 1, 8)), np.zeros((B, N, 8)), np.zeros((B, N, 2))
+            L1, L2 = np.zeros((B, N, 8)), np.zeros((B, N, 8))
+        else:
+            X, Cc, U, L1, L2 = (np.ascontiguousarray(warm[k], float).copy() for k in ("X", "C", "U", "L1", "L2"))
+        u0, st = np.zeros((B, 2)), np.zeros((B, 7))
+        lib().oracle_solve_batch(C.byref(self.p), C.byref(self.o), _p(self.tab), self.nt, int(N), int(B), _p(x0),
+                                 _p(uprev), int(warm is not None), _p(X), _p(Cc), _p(U), _p(L1), _p(L2), _p(u0),
+                                 _p(st), int(nthreads))
+        return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
+                    kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int))
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())
