@@ -111,8 +111,9 @@ int ltompc_set_initial_guess(ltompc_handle h, const double* x0);
 int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status, int* iters);
 
 /* Same, device pointers, enqueue only (x0_dev: batch x 8, u0_dev: batch x 2, row-major, on the handle's
- * device).  Converged instances idle; the call enqueues `max_iter` iterations unless ltompc_make_step_dev
- * finds all instances finished earlier (it polls a device counter every `poll_every` iterations). */
+ * device; u0_dev may be NULL).  Converged instances idle; the host stops launching iterations once a polled
+ * device counter says every instance has terminated (ltompc_set_poll_every).  Kernels run on the handle's
+ * stream; the call returns after the last poll, the final u0 store may still be in flight on that stream. */
 int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev);
 
 /* Predicted trajectories of the last solve (do_mpc: mpc.opt_x_num['_x', k, 0, -1], ['_u', k, 0]).
@@ -140,9 +141,30 @@ int ltompc_plant_step_dev(ltompc_handle h, const double* x_dev, const double* u_
  * x: batch x 8 -> alpha: batch x 2 (front, rear), Fy: batch x 2.  Host pointers, computed on the device. */
 int ltompc_slip_forces(ltompc_handle h, const double* x, int batch, double* alpha, double* Fy);
 
-/* Timing of the last make_step: device time in ms per kernel class (eval, riccati, expand, linesearch, pick)
- * measured with HIP events on the handle's stream; launches = kernel launches issued. */
-int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel5, int* launches, int* ip_iterations);
+/* Device-pointer form of ltompc_set_initial_guess (enqueue only). */
+int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev);
+
+/* Per-instance counters of the last solve: Hessian-regularisation retries, failed line searches (host, out). */
+int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
+
+/* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
+ * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:
+ * index 0 eval, 1 riccati, 2 expand, 3 linesearch, 4 pick, 5 update.  launches / ip_iterations refer to the
+ * last make_step.  Any output may be NULL. */
+int ltompc_set_profiling(ltompc_handle h, int on);
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_kernel6, int* launches,
+                      int* ip_iterations);
+
+/* make_step polls the device's count of unfinished instances every n interior-point iterations (default 4). */
+int ltompc_set_poll_every(ltompc_handle h, int n);
+
+/* Test hook (not part of the reference surface): model derivatives at n points, computed by the same device
+ * functions the solver kernels use.  x, lam: n x 8 -> f: n x 8; J (df/dx), H (sum_i lam_i d2f_i): n x 8 x 8;
+ * cost value / gradient / Hessian of lterm and mterm: n x 2 [x 8 [x 8]]; constraints gL, gR+, gR-:
+ * n x 3 [x 8 [x 8]].  eps = table smoothing length. */
+int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const double* lam, double* f,
+                      double* J, double* H, double* cval, double* cgrad, double* cH, double* gval,
+                      double* ggrad, double* gH);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,1109 @@
+// kernels.h — HIP kernels of the batched interior-point NLP solver (gfx950).
+//
+// One make_step (reference src/mpc.py:142, do_mpc MPC.make_step -> IPOPT) = up to max_iter interior-point
+// iterations, each a fixed sequence of kernels over the whole batch:
+//
+//   k_eval    thread = (interval k, instance b)   derivatives of dynamics / cost / constraints at the Radau point
+//                                                 and the next node, KKT residual partials, elimination of the
+//                                                 collocation variables  -> stage QP blocks (A,B,b,Q,S,R,q,r)
+//   k_riccati thread = instance b                 KKT error, termination, barrier update, Riccati backward sweep
+//                                                 (with inertia-correcting regularisation) and forward rollout
+//   k_expand  thread = (k, b)                     collocation steps, collocation multipliers, slack / inequality
+//                                                 multiplier steps, fraction-to-boundary partial minima
+//   k_linesearch thread = (k, b)                  filter measures (theta, cost, sum log t) for all step candidates
+//   k_pick    thread = b                          filter acceptance test, step length, filter / stall bookkeeping
+//   k_update  thread = (k, b)                     z += alpha dz
+//
+// HBM layout: every per-(k,b) quantity is a plane [field][k][Bp] with the instance index fastest, so that the
+// 64 lanes of a wavefront (consecutive b, same k) read/write 512 contiguous bytes per field.
+#pragma once
+#include "model.h"
+
+namespace ltompc {
+
+constexpr int FILTER_MAX = 16;
+constexpr int MAX_LS = 12;
+
+// fields of the stage-QP buffer written by k_eval and read by k_riccati
+enum : int {
+  QP_A = 0,            // 64  A_k   (dx+ = A dx + B du + b)
+  QP_B = 64,           // 16
+  QP_b = 80,           // 8
+  QP_Q = 88,           // 36  condensed-collocation part of the (x_k,x_k) block
+  QP_S = 124,          // 16  (u_k, x_k)
+  QP_R = 140,          // 3   (u_k, u_k) incl. input-bound barrier
+  QP_q0 = 143,         // 8   gradient = q0 + mu * q1
+  QP_q1 = 151,         // 8
+  QP_r0 = 159,         // 2
+  QP_r1 = 161,         // 2
+  QP_Qx = 163,         // 36  node block of x_{k+1} (cost + constraints + bounds + lambda2-weighted dynamics)
+  QP_qx0 = 199,        // 8
+  QP_qx1 = 207,        // 8
+  QP_NF = 215
+};
+// fields of the Riccati buffer written by k_riccati and read by k_expand; stage index 0..N
+enum : int { RC_K = 0, RC_Kv = 16, RC_kff = 20, RC_P = 22, RC_Pxv = 58, RC_pp = 74, RC_NF = 82 };
+// residual partials written by k_eval (per k,b)
+enum : int { RS_rd = 0, RS_rp, RS_cmax, RS_cmin, RS_smult, RS_cost, RS_NF };
+// step partials written by k_expand
+enum : int { SP_apri = 0, SP_adua, SP_gphid, SP_NF };
+// per-instance double state
+enum : int {
+  ST_MU = 0, ST_EPS, ST_EPS_NEXT, ST_DW_LAST, ST_FORCE_REG, ST_ALPHA, ST_ADUA, ST_E0, ST_OBJ, ST_TAU,
+  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_NF
+};
+// per-instance int state
+enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_NF };
+
+struct Work {
+  int N, B, Bp;
+  // iterate
+  double *X, *C, *U, *L1, *L2, *T, *NU;
+  // steps
+  double *dX, *dC, *dU, *nL1, *nL2, *dT, *dNU;
+  // buffers
+  double *QP, *RC, *RS, *SP, *LS;
+  double *x0, *uprev;  // [8][Bp], [2][Bp]
+  double *st;          // [ST_NF][Bp]
+  double *filt;        // [2*FILTER_MAX][Bp]
+  int *si;             // [SI_NF][Bp]
+  int *active;         // [max_iter+2] number of unfinished instances after iteration i
+};
+
+struct Consts {
+  ltompc_params p;
+  ltompc_options o;
+  Tables T;
+  Bounds bd;
+};
+
+#define PL(base, f, k, NK) ((base)[((size_t)(f) * (NK) + (k)) * W.Bp + b])
+
+// ------------------------------------------------------------------------------------------ small dense LA
+__device__ __forceinline__ bool lu8(double* M) {  // in place, no pivoting (M = 4.5 I + 2 E2 E1)
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    double pv = M[k * 8 + k];
+    ok = ok && (fabs(pv) > 1e-12);
+    double ip = 1.0 / pv;
+#pragma unroll
+    for (int i = k + 1; i < 8; i++) {
+      double l = M[i * 8 + k] * ip;
+      M[i * 8 + k] = l;
+#pragma unroll
+      for (int j = k + 1; j < 8; j++) M[i * 8 + j] -= l * M[k * 8 + j];
+    }
+  }
+  return ok;
+}
+__device__ __forceinline__ void lu8_solve(const double* M, double* v) {
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+#pragma unroll
+    for (int i = k + 1; i < 8; i++) v[i] -= M[i * 8 + k] * v[k];
+#pragma unroll
+  for (int i = 7; i >= 0; i--) {
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) v[i] -= M[i * 8 + j] * v[j];
+    v[i] /= M[i * 8 + i];
+  }
+}
+__device__ __forceinline__ void lu8_solve_t(const double* M, double* v) {  // M^T x = v
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int j = 0; j < i; j++) v[i] -= M[j * 8 + i] * v[j];
+    v[i] /= M[i * 8 + i];
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; i--)
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) v[i] -= M[j * 8 + i] * v[j];
+}
+__device__ __forceinline__ double sym_get(const double* H, int i, int j) { return H[sidx(i, j)]; }
+
+// ------------------------------------------------------------------------------------------ slot linearisation
+// Slot k owns (u_k, c_k, x_{k+1}) and the collocation equations of interval k in do_mpc's Radau-IIA(2) form
+//   G1 = h f(c,u) + 2 x_k - 1.5 c - 0.5 x+ = 0 ,  G2 = h f(x+,u) - 2 x_k + 4.5 c - 2.5 x+ = 0   
+struct Slot {
+  double xk[8], xp[8], c[8], u[2];
+  double E1[64], E2[64], G1[8], G2[8];
+  double Hc[36], gc0[8], gc1[8];     // QP block of c_k : gradient = gc0 + mu gc1 (barrier terms included)
+  double Hxp[36], gxp0[8], gxp1[8];  // QP block of x_{k+1}
+  double Du[2], gub0[2], gub1[2];    // input-bound barrier
+  double dcd[8], dxd[8], dud[2];     // parts of grad_z L that do not involve the collocation multipliers
+  double gcost[8];
+  double gs[3], gn[3], gm[3];        // gradients of gL, gR+, gR-
+  double h[MAX_NI];
+  double cost;
+  bool nl;
+};
+
+template <bool WITH_DUAL>
+__device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
+  const int N = W.N;
+  const double hdt = K.o.t_step;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    S.xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+    S.xp[i] = PL(W.X, i, k + 1, N + 1);
+    S.c[i] = PL(W.C, i, k, N);
+  }
+  S.u[0] = PL(W.U, 0, k, N), S.u[1] = PL(W.U, 1, k, N);
+  double l1[8], l2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N);
+#pragma unroll
+  for (int i = 0; i < 36; i++) S.Hc[i] = 0.0, S.Hxp[i] = 0.0;
+  double f1[8], f2[8], J[48];
+  rhs_derivs(K.p, K.T, eps, S.c, f1, J, l1, hdt, S.Hc);
+#pragma unroll
+  for (int i = 0; i < 64; i++) S.E1[i] = 0.0, S.E2[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 48; i++) S.E1[i] = hdt * J[i];
+  rhs_derivs(K.p, K.T, eps, S.xp, f2, J, l2, hdt, S.Hxp);
+#pragma unroll
+  for (int i = 0; i < 48; i++) S.E2[i] = hdt * J[i];
+  f1[6] = f2[6] = S.u[0], f1[7] = f2[7] = S.u[1];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    S.E1[i * 8 + i] -= 1.5, S.E2[i * 8 + i] -= 2.5;
+    S.G1[i] = hdt * f1[i] + 2.0 * S.xk[i] - 1.5 * S.c[i] - 0.5 * S.xp[i];
+    S.G2[i] = hdt * f2[i] - 2.0 * S.xk[i] + 4.5 * S.c[i] - 2.5 * S.xp[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) S.gcost[i] = 0.0, S.gc0[i] = 0.0, S.gc1[i] = 0.0, S.gxp1[i] = 0.0, S.dcd[i] = 0.0;
+  S.cost = cost_eval(K.p, K.T, eps, S.xp, k == N - 1, S.gcost, S.Hxp);
+#pragma unroll
+  for (int i = 0; i < 8; i++) S.gxp0[i] = S.gcost[i], S.dxd[i] = S.gcost[i];
+  S.Du[0] = S.Du[1] = 0.0, S.gub0[0] = S.gub0[1] = 0.0, S.gub1[0] = S.gub1[1] = 0.0, S.dud[0] = S.dud[1] = 0.0;
+  // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
+  // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
+  const Bounds& bd = K.bd;
+  int m = 0;
+  for (int i = 0; i < bd.n_ub; i++, m++) {
+    int j = bd.ub_idx[i];
+    double sg = bd.ub_sgn[i];
+    double hv = bound_h(sg, bd.ub_val[i], S.u[j]);
+    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    S.h[m] = hv;
+    S.Du[j] += nu * it, S.gub0[j] += sg * nu * (hv + t) * it, S.gub1[j] += sg * it;
+    if (WITH_DUAL) S.dud[j] += sg * nu;
+  }
+  for (int i = 0; i < bd.n_xb; i++, m++) {
+    int j = bd.xb_idx[i];
+    double sg = bd.xb_sgn[i];
+    double hv = bound_h(sg, bd.xb_val[i], S.c[j]);
+    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    S.h[m] = hv;
+    S.Hc[sidx(j, j)] += nu * it, S.gc0[j] += sg * nu * (hv + t) * it, S.gc1[j] += sg * it;
+    if (WITH_DUAL) S.dcd[j] += sg * nu;
+  }
+  for (int i = 0; i < bd.n_xb; i++, m++) {
+    int j = bd.xb_idx[i];
+    double sg = bd.xb_sgn[i];
+    double hv = bound_h(sg, bd.xb_val[i], S.xp[j]);
+    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    S.h[m] = hv;
+    S.Hxp[sidx(j, j)] += nu * it, S.gxp0[j] += sg * nu * (hv + t) * it, S.gxp1[j] += sg * it;
+    if (WITH_DUAL) S.dxd[j] += sg * nu;
+  }
+  S.nl = (k + 1 <= N - 1);  // nl_cons are checked at nodes 1..N-1 (node 0 is data, node N is not checked)
+  if (S.nl) {
+    double gv[3], hss[3], hmm[3];
+    cons_eval(K.p, K.T, eps, S.xp, gv, S.gs, S.gn, S.gm, hss, hmm);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int mm = m + q;
+      double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N), it = 1.0 / t;
+      double Sg = nu * it, s0 = nu * (gv[q] + t) * it;
+      S.h[mm] = gv[q];
+      double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        S.gxp0[a] += s0 * g3[a], S.gxp1[a] += it * g3[a];
+        if (WITH_DUAL) S.dxd[a] += nu * g3[a];
+#pragma unroll
+        for (int c = 0; c <= a; c++) S.Hxp[sidx(a, c)] += Sg * g3[a] * g3[c];
+      }
+      S.Hxp[sidx(0, 0)] += nu * hss[q];
+      S.Hxp[sidx(2, 2)] += nu * hmm[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3; q++) S.h[m + q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
+  }
+}
+
+// Elimination of the collocation point: with M8 = 4.5 I + 2 E2 E1,
+//   M8 dc = (2I - 4E2) dx - (I + 2E2) Bu du - G2 - 2 E2 G1 ,   dx+ = 2 (E1 dc + 2 dx + Bu du + G1)
+// Y = [Ac | Bc | bc] (8 x 11), AB = [A | B | b] (8 x 11); M8 holds its LU factors on return.
+__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, double* M8, double* Y, double* AB) {
+  const double hdt = K.o.t_step;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      double s = (i == j) ? 4.5 : 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; l++) s += 2.0 * S.E2[i * 8 + l] * S.E1[l * 8 + j];
+      M8[i * 8 + j] = s;
+    }
+  bool ok = lu8(M8);
+#pragma unroll
+  for (int col = 0; col < 11; col++) {
+    double v[8];
+    if (col < 8) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = ((i == col) ? 2.0 : 0.0) - 4.0 * S.E2[i * 8 + col];
+    } else if (col < 10) {
+      int j = 6 + col - 8;
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = -hdt * (((i == j) ? 1.0 : 0.0) + 2.0 * S.E2[i * 8 + j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        double s = -S.G2[i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s -= 2.0 * S.E2[i * 8 + l] * S.G1[l];
+        v[i] = s;
+      }
+    }
+    lu8_solve(M8, v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) Y[i * 11 + col] = v[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double s;
+      if (col < 8) s = (i == col) ? 2.0 : 0.0;
+      else if (col < 10) s = (i == 6 + col - 8) ? hdt : 0.0;
+      else s = S.G1[i];
+#pragma unroll
+      for (int l = 0; l < 8; l++) s += S.E1[i * 8 + l] * v[l];
+      AB[i * 11 + col] = 2.0 * s;
+    }
+  }
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------ k_init
+// Cold: do_mpc set_initial_guess (every state slot = x0, inputs 0, multipliers 0).  Warm: keep the previous
+// primal/dual solution un-shifted (do_mpc), node 0 := new x0.  Slacks t = max(-h, bound_push), nu = mu/t.
+__global__ void k_init(Consts K, Work W, int cold) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  double x0[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.X, i, 0, N + 1) = x0[i];
+  }
+  if (cold) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PL(W.X, i, k + 1, N + 1) = x0[i], PL(W.C, i, k, N) = x0[i];
+      PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
+    }
+    PL(W.U, 0, k, N) = 0.0, PL(W.U, 1, k, N) = 0.0;
+  }
+  double xp[8], c[8], u[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xp[i] = cold ? x0[i] : PL(W.X, i, k + 1, N + 1), c[i] = cold ? x0[i] : PL(W.C, i, k, N);
+  u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
+  const double mu = K.o.mu_init;
+  const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
+  const Bounds& bd = K.bd;
+  int m = 0;
+  auto put = [&](int mm, double hv) {
+    double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
+    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
+  };
+  for (int i = 0; i < bd.n_ub; i++, m++) put(m, bound_h(bd.ub_sgn[i], bd.ub_val[i], u[bd.ub_idx[i]]));
+  for (int i = 0; i < bd.n_xb; i++, m++) put(m, bound_h(bd.xb_sgn[i], bd.xb_val[i], c[bd.xb_idx[i]]));
+  for (int i = 0; i < bd.n_xb; i++, m++) put(m, bound_h(bd.xb_sgn[i], bd.xb_val[i], xp[bd.xb_idx[i]]));
+  double gv[3] = {-1.0, -1.0, -1.0};
+  if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+  for (int q = 0; q < 3; q++) put(m + q, gv[q]);
+  if (k == 0) {
+    double* st = W.st;
+    st[(size_t)ST_MU * W.Bp + b] = mu, st[(size_t)ST_EPS * W.Bp + b] = eps, st[(size_t)ST_EPS_NEXT * W.Bp + b] = eps;
+    st[(size_t)ST_DW_LAST * W.Bp + b] = 0.0, st[(size_t)ST_FORCE_REG * W.Bp + b] = 0.0;
+    st[(size_t)ST_ALPHA * W.Bp + b] = 0.0, st[(size_t)ST_ADUA * W.Bp + b] = 0.0;
+    st[(size_t)ST_E0 * W.Bp + b] = 1e300, st[(size_t)ST_OBJ * W.Bp + b] = 0.0, st[(size_t)ST_TAU * W.Bp + b] = 0.99;
+    st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
+    st[(size_t)ST_DW * W.Bp + b] = 0.0;
+    for (int i = 0; i < SI_NF; i++) W.si[(size_t)i * W.Bp + b] = 0;
+    W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ k_eval
+__global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  const double hdt = K.o.t_step;
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  Slot S;
+  linearise_slot<true>(K, W, k, b, eps, S);
+  // ---- residual partials (IPOPT's E_mu ingredients) ----
+  {
+    double l1[8], l2[8], rd = 0.0, rp = 0.0, sm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N);
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      double rcx = S.dcd[a] + 4.5 * l2[a];
+      double rxp = S.dxd[a] - 0.5 * l1[a];
+#pragma unroll
+      for (int i = 0; i < 8; i++) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
+      if (k + 1 < N) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);
+      rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
+      rp = fmax(rp, fmax(fabs(S.G1[a]), fabs(S.G2[a])));
+      sm += fabs(l1[a]) + fabs(l2[a]);
+    }
+    double cost = S.cost;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double v = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+      double du = S.u[i] - v;
+      cost += K.p.r_du[i] * du * du;
+      double ru = S.dud[i] + 2.0 * K.p.r_du[i] * du + hdt * (l1[6 + i] + l2[6 + i]);
+      if (k + 1 < N) ru -= 2.0 * K.p.r_du[i] * (PL(W.U, i, k + 1, N) - S.u[i]);
+      rd = fmax(rd, fabs(ru));
+    }
+    double cmax = 0.0, cmin = 1e300;
+    int ni = K.bd.ni, nact = S.nl ? ni : ni - 3;
+    for (int m = 0; m < nact; m++) {
+      double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+      rp = fmax(rp, fabs(S.h[m] + t));
+      cmax = fmax(cmax, t * nu), cmin = fmin(cmin, t * nu);
+      sm += fabs(nu);
+    }
+    PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
+    PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
+  }
+  // ---- eliminate the collocation point, project its QP block onto (x_k, u_k) ----
+  double M8[64], Y[88], AB[88];
+  condense_slot(K, S, M8, Y, AB);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) PL(W.QP, QP_A + i * 8 + j, k, N) = AB[i * 11 + j];
+    PL(W.QP, QP_B + i * 2 + 0, k, N) = AB[i * 11 + 8], PL(W.QP, QP_B + i * 2 + 1, k, N) = AB[i * 11 + 9];
+    PL(W.QP, QP_b + i, k, N) = AB[i * 11 + 10];
+  }
+  double HY[88];  // Hc * [Ac | Bc | bc]
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int col = 0; col < 11; col++) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; l++) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
+      HY[i * 11 + col] = s;
+    }
+  // Q = Ac^T Hc Ac, S = Bc^T Hc Ac, R = Bc^T Hc Bc + Du; q = [Ac|Bc]^T (Hc bc + gc0 + mu gc1) (+ gub)
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      if (j > i) continue;
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l < 8; l++) s += Y[l * 11 + i] * HY[l * 11 + j];
+      if (i < 8) PL(W.QP, QP_Q + sidx(i, j), k, N) = s;
+      else if (j < 8) PL(W.QP, QP_S + (i - 8) * 8 + j, k, N) = s;
+      else PL(W.QP, QP_R + sidx(i - 8, j - 8), k, N) = s + ((i == j) ? S.Du[i - 8] : 0.0);
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l = 0; l < 8; l++) s0 += Y[l * 11 + i] * (HY[l * 11 + 10] + S.gc0[l]), s1 += Y[l * 11 + i] * S.gc1[l];
+    if (i < 8) PL(W.QP, QP_q0 + i, k, N) = s0, PL(W.QP, QP_q1 + i, k, N) = s1;
+    else PL(W.QP, QP_r0 + i - 8, k, N) = s0 + S.gub0[i - 8], PL(W.QP, QP_r1 + i - 8, k, N) = s1 + S.gub1[i - 8];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; i++) PL(W.QP, QP_Qx + i, k, N) = S.Hxp[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) PL(W.QP, QP_qx0 + i, k, N) = S.gxp0[i], PL(W.QP, QP_qx1 + i, k, N) = S.gxp1[i];
+}
+
+// ------------------------------------------------------------------------------------------ k_riccati
+// One thread per instance.  State of the recursion is (x_k, v_k = u_{k-1}) because do_mpc's rterm penalises
+// u_k - u_{k-1} (controller.py:40-41): stage cost r |u_k - v_k|^2, v_{k+1} = u_k.
+__global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+#define STD(f) st[(size_t)(f) * W.Bp + b]
+#define STI(f) si[(size_t)(f) * W.Bp + b]
+  if (STI(SI_DONE)) return;
+  const ltompc_options& o = K.o;
+  // ---- reduce residual partials, KKT error, termination (IPOPT eq. (5),(6)) ----
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, smult = 0.0;
+  double obj;
+  {
+    double x0[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
+    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);  // lterm(x_0), constant
+  }
+  for (int k = 0; k < N; k++) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+    smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  }
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;  // multipliers counted (last slot has no nl constraints)
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+  int iters = STI(SI_ITERS);
+  int term = -1;
+  if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+  else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+  else {
+    if (E0 <= o.acceptable_tol) {
+      int na = STI(SI_NACC) + 1;
+      STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE;
+    } else STI(SI_NACC) = 0;
+    if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+  }
+  if (term >= 0) {
+    STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+    return;
+  }
+  atomicAdd(&W.active[it_index], 1);
+  // ---- monotone barrier update (IPOPT eq. (7)) ----
+  bool mu_changed = false;
+  while (Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (mu_changed) {
+    STD(ST_MU) = mu;
+    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+    STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+  }
+  STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  // ---- backward sweep, retried with Hessian regularisation until every Huu is positive definite ----
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  int tries = 0;
+  bool numerical = false;
+  for (;;) {
+    bool ok = true;
+    double P[64], Pxv[16], Pvv[4], pp[8], pv[2];
+    // terminal node block (slot N-1)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) P[i * 8 + j] = PL(W.QP, QP_Qx + sidx(i, j), N - 1, N) + ((i == j) ? delta_w : 0.0);
+      pp[i] = PL(W.QP, QP_qx0 + i, N - 1, N) + mu * PL(W.QP, QP_qx1 + i, N - 1, N);
+      Pxv[i * 2] = Pxv[i * 2 + 1] = 0.0;
+    }
+    Pvv[0] = Pvv[1] = Pvv[2] = Pvv[3] = 0.0, pv[0] = pv[1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) PL(W.RC, RC_P + sidx(i, j), N, N + 1) = P[i * 8 + j];
+      PL(W.RC, RC_Pxv + i * 2, N, N + 1) = 0.0, PL(W.RC, RC_Pxv + i * 2 + 1, N, N + 1) = 0.0;
+      PL(W.RC, RC_pp + i, N, N + 1) = pp[i];
+    }
+    for (int k = N - 1; k >= 0; k--) {
+      double A[64], Bm[16], bv[8];
+#pragma unroll
+      for (int i = 0; i < 64; i++) A[i] = PL(W.QP, QP_A + i, k, N);
+#pragma unroll
+      for (int i = 0; i < 16; i++) Bm[i] = PL(W.QP, QP_B + i, k, N);
+#pragma unroll
+      for (int i = 0; i < 8; i++) bv[i] = PL(W.QP, QP_b + i, k, N);
+      double PA[64], PB[16], Pb[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += P[i * 8 + l] * A[l * 8 + j];
+          PA[i * 8 + j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += P[i * 8 + l] * Bm[l * 2 + j];
+          PB[i * 2 + j] = s;
+        }
+        double s = pp[i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += P[i * 8 + l] * bv[l];
+        Pb[i] = s;
+      }
+      double Huu[4], Hux[16], gu[2], uk[2], vk[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        uk[i] = PL(W.U, i, k, N);
+        vk[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          double s = PL(W.QP, QP_R + sidx(i, j), k, N) + Pvv[i * 2 + j];
+#pragma unroll
+          for (int l = 0; l < 8; l++)
+            s += Bm[l * 2 + i] * PB[l * 2 + j] + Bm[l * 2 + i] * Pxv[l * 2 + j] + Pxv[l * 2 + i] * Bm[l * 2 + j];
+          Huu[i * 2 + j] = s;
+        }
+        Huu[i * 2 + i] += r2[i] + delta_w;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = PL(W.QP, QP_S + i * 8 + j, k, N);
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * PA[l * 8 + j] + Pxv[l * 2 + i] * A[l * 8 + j];
+          Hux[i * 8 + j] = s;
+        }
+        double s = PL(W.QP, QP_r0 + i, k, N) + mu * PL(W.QP, QP_r1 + i, k, N) + r2[i] * (uk[i] - vk[i]) + pv[i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * Pb[l] + Pxv[l * 2 + i] * bv[l];
+        gu[i] = s;
+      }
+      double Hxx[64], gx[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = PL(W.QP, QP_Q + sidx(i, j), k, N) + ((i == j) ? delta_w : 0.0);
+          if (k > 0) s += PL(W.QP, QP_Qx + sidx(i, j), k - 1, N);
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += A[l * 8 + i] * PA[l * 8 + j];
+          Hxx[i * 8 + j] = s;
+        }
+        double s = PL(W.QP, QP_q0 + i, k, N) + mu * PL(W.QP, QP_q1 + i, k, N);
+        if (k > 0) s += PL(W.QP, QP_qx0 + i, k - 1, N) + mu * PL(W.QP, QP_qx1 + i, k - 1, N);
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += A[l * 8 + i] * Pb[l];
+        gx[i] = s;
+      }
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      if (!(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det)) {
+        ok = false;
+        break;
+      }
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kx[16], Kv[4], kff[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) Kx[i * 8 + j] = -(Hi[i * 2 + 0] * Hux[0 * 8 + j] + Hi[i * 2 + 1] * Hux[1 * 8 + j]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) Kv[i * 2 + j] = Hi[i * 2 + j] * r2[j];
+        kff[i] = -(Hi[i * 2 + 0] * gu[0] + Hi[i * 2 + 1] * gu[1]);
+      }
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) P[i * 8 + j] = Hxx[i * 8 + j] + Hux[0 * 8 + i] * Kx[0 * 8 + j] + Hux[1 * 8 + i] * Kx[1 * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 2; j++) Pxv[i * 2 + j] = Hux[0 * 8 + i] * Kv[0 * 2 + j] + Hux[1 * 8 + i] * Kv[1 * 2 + j];
+        pp[i] = gx[i] + Hux[0 * 8 + i] * kff[0] + Hux[1 * 8 + i] * kff[1];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) Pvv[i * 2 + j] = ((i == j) ? r2[i] : 0.0) - r2[i] * Kv[i * 2 + j];
+        pv[i] = gv[i] - r2[i] * kff[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+          double s = 0.5 * (P[i * 8 + j] + P[j * 8 + i]);
+          P[i * 8 + j] = s, P[j * 8 + i] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < 16; i++) PL(W.RC, RC_K + i, k, N + 1) = Kx[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) PL(W.RC, RC_Kv + i, k, N + 1) = Kv[i];
+      PL(W.RC, RC_kff + 0, k, N + 1) = kff[0], PL(W.RC, RC_kff + 1, k, N + 1) = kff[1];
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+          for (int j = 0; j <= i; j++) PL(W.RC, RC_P + sidx(i, j), k, N + 1) = P[i * 8 + j];
+          PL(W.RC, RC_Pxv + i * 2, k, N + 1) = Pxv[i * 2], PL(W.RC, RC_Pxv + i * 2 + 1, k, N + 1) = Pxv[i * 2 + 1];
+          PL(W.RC, RC_pp + i, k, N + 1) = pp[i];
+        }
+      }
+    }
+    if (ok) break;
+    // inertia correction schedule (Waechter & Biegler 2006, Algorithm IC)
+    if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+    else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+    STI(SI_NREG) += 1;
+    if (++tries > 40 || delta_w > 1e20) {
+      numerical = true;
+      break;
+    }
+  }
+  if (numerical) {
+    STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+    return;
+  }
+  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w;
+  STD(ST_DW) = delta_w;
+  // ---- forward rollout ----
+  double dx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; i++) PL(W.dX, i, 0, N + 1) = 0.0;
+  for (int k = 0; k < N; k++) {
+    double du[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double s = PL(W.RC, RC_kff + i, k, N + 1) + PL(W.RC, RC_Kv + i * 2, k, N + 1) * dv[0] + PL(W.RC, RC_Kv + i * 2 + 1, k, N + 1) * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += PL(W.RC, RC_K + i * 8 + j, k, N + 1) * dx[j];
+      du[i] = s;
+    }
+    double dn[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double s = PL(W.QP, QP_b + i, k, N) + PL(W.QP, QP_B + i * 2, k, N) * du[0] + PL(W.QP, QP_B + i * 2 + 1, k, N) * du[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += PL(W.QP, QP_A + i * 8 + j, k, N) * dx[j];
+      dn[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) dx[i] = dn[i], PL(W.dX, i, k + 1, N + 1) = dn[i];
+    dv[0] = du[0], dv[1] = du[1];
+    PL(W.dU, 0, k, N) = du[0], PL(W.dU, 1, k, N) = du[1];
+  }
+  STI(SI_STEP) = 1;
+}
+
+// ------------------------------------------------------------------------------------------ k_expand
+__global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
+  Slot S;
+  linearise_slot<false>(K, W, k, b, eps, S);
+  double M8[64], Y[88], AB[88];
+  condense_slot(K, S, M8, Y, AB);
+  double dxk[8], dxp[8], du[2], dc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) dxk[i] = PL(W.dX, i, k, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+  du[0] = PL(W.dU, 0, k, N), du[1] = PL(W.dU, 1, k, N);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = Y[i * 11 + 10] + Y[i * 11 + 8] * du[0] + Y[i * 11 + 9] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += Y[i * 11 + j] * dxk[j];
+    dc[i] = s;
+    PL(W.dC, i, k, N) = s;
+  }
+  // costate pi_{k+1} = P_{k+1} dx_{k+1} + Pxv_{k+1} du_k + p_{k+1}
+  double pi[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = PL(W.RC, RC_pp + i, k + 1, N + 1) + PL(W.RC, RC_Pxv + i * 2, k + 1, N + 1) * du[0] +
+               PL(W.RC, RC_Pxv + i * 2 + 1, k + 1, N + 1) * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += PL(W.RC, RC_P + sidx(i, j), k + 1, N + 1) * dxp[j];
+    pi[i] = s;
+  }
+  // new collocation multipliers:  M8^T l2 = -(Hc dc + gc) - 2 E1^T pi ;  l1 = 2 (E2^T l2 + pi)
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = S.gc0[i] + mu * S.gc1[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += sym_get(S.Hc, i, j) * dc[j] + 2.0 * S.E1[j * 8 + i] * pi[j];
+    v[i] = -s;
+  }
+  lu8_solve_t(M8, v);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = pi[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += S.E2[j * 8 + i] * v[j];
+    PL(W.nL1, i, k, N) = 2.0 * s;
+    PL(W.nL2, i, k, N) = v[i];
+  }
+  // slack / multiplier steps, fraction to the boundary, directional derivative of the barrier objective
+  double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double v0 = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+    double dv0 = k ? PL(W.dU, i, k - 1, N) : 0.0;
+    gphid += 2.0 * K.p.r_du[i] * (S.u[i] - v0) * (du[i] - dv0);
+  }
+#pragma unroll
+  for (int a = 0; a < 8; a++) gphid += S.gcost[a] * dxp[a];
+  const Bounds& bd = K.bd;
+  const int ni = bd.ni, nact = S.nl ? ni : ni - 3;
+  for (int m = 0; m < ni; m++) {
+    if (m >= nact) {
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+      continue;
+    }
+    double gd;
+    if (m < bd.n_ub) gd = bd.ub_sgn[m] * du[bd.ub_idx[m]];
+    else if (m < bd.n_ub + bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub] * dc[bd.xb_idx[m - bd.n_ub]];
+    else if (m < bd.n_ub + 2 * bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub - bd.n_xb] * dxp[bd.xb_idx[m - bd.n_ub - bd.n_xb]];
+    else {
+      int q = m - bd.n_ub - 2 * bd.n_xb;
+      gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
+    }
+    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+    double dtt = -(S.h[m] + t) - gd;
+    double dn = (mu - nu * dtt) / t - nu;
+    PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+    if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+    if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+    gphid -= mu * dtt / t;
+  }
+  PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
+}
+
+// ------------------------------------------------------------------------------------------ k_linesearch
+// candidate 0 is the current point (alpha = 0); candidate l >= 1 has alpha = a_pri * 2^-(l-1).
+// LS plane layout: [3 * (n_ls + 1)][N][Bp] : theta, cost, sum log t per candidate.
+__global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const double hdt = K.o.t_step;
+  double a_pri = 1.0;
+  for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
+  double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+    dxk[i] = PL(W.dX, i, k, N + 1);
+    xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+    c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
+    v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+    dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
+  }
+  const Bounds& bd = K.bd;
+  const int ni = bd.ni;
+  const bool nl = (k + 1 <= N - 1);
+  const int n_ls = K.o.n_linesearch;
+  double alpha = 0.0;
+  for (int l = 0; l <= n_ls; l++) {
+    double txk[8], txp[8], tc[8], tu[2], tv[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
+    double f1[8], f2[8];
+    rhs_val(K.p, K.T, eps, tc, tu, f1);
+    rhs_val(K.p, K.T, eps, txp, tu, f2);
+    double th = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
+      th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
+    }
+    double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
+#pragma unroll
+    for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
+    double sl = 0.0;
+    int m = 0;
+    for (int i = 0; i < bd.n_ub; i++, m++) {
+      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
+      th += fabs(bound_h(bd.ub_sgn[i], bd.ub_val[i], tu[bd.ub_idx[i]]) + t), sl += log(t);
+    }
+    for (int i = 0; i < bd.n_xb; i++, m++) {
+      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
+      th += fabs(bound_h(bd.xb_sgn[i], bd.xb_val[i], tc[bd.xb_idx[i]]) + t), sl += log(t);
+    }
+    for (int i = 0; i < bd.n_xb; i++, m++) {
+      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
+      th += fabs(bound_h(bd.xb_sgn[i], bd.xb_val[i], txp[bd.xb_idx[i]]) + t), sl += log(t);
+    }
+    if (nl) {
+      double gv[3];
+      cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
+        th += fabs(gv[q] + t), sl += log(t);
+      }
+    }
+    (void)ni;
+    PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
+    alpha = (l == 0) ? a_pri : 0.5 * alpha;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ k_pick
+// Filter line search of Waechter & Biegler 2006 (no second-order correction, no restoration phase).
+__global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  if (STI(SI_DONE)) return;
+  const ltompc_options& o = K.o;
+  const double mu = STD(ST_MU);
+  double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
+  for (int k = 0; k < N; k++) {
+    a_pri = fmin(a_pri, PL(W.SP, SP_apri, k, N)), a_dua = fmin(a_dua, PL(W.SP, SP_adua, k, N));
+    gphid += PL(W.SP, SP_gphid, k, N);
+  }
+  // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
+  double c00;
+  {
+    double x0[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
+    c00 = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
+  }
+  auto measures = [&](int l, double& th, double& ph) {
+    double t = 0.0, c = c00, s = 0.0;
+    for (int k = 0; k < N; k++) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
+    th = t, ph = c - mu * s;
+  };
+  double th0, ph0;
+  measures(0, th0, ph0);
+  double theta0 = STD(ST_THETA0);
+  int nfilt = STI(SI_NFILT);
+  if (theta0 < 0.0) {
+    theta0 = th0;
+    STD(ST_THETA0) = theta0, STD(ST_THMAX) = 1e4 * fmax(1.0, theta0), STD(ST_THMIN) = 1e-4 * fmax(1.0, theta0);
+    nfilt = 0;
+  }
+  const double theta_max = STD(ST_THMAX), theta_min = STD(ST_THMIN);
+  const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0;
+  bool accepted = false;
+  double alpha = a_pri;
+  const int n_ls = o.n_linesearch;
+  for (int l = 0; l < n_ls; l++, alpha *= 0.5) {
+    double th, ph;
+    measures(l + 1, th, ph);
+    if (!isfinite(th) || !isfinite(ph) || th > theta_max) continue;
+    bool in_filter = false;
+    for (int f = 0; f < nfilt; f++)
+      if (th >= W.filt[(size_t)(2 * f) * W.Bp + b] && ph >= W.filt[(size_t)(2 * f + 1) * W.Bp + b]) {
+        in_filter = true;
+        break;
+      }
+    if (in_filter) continue;
+    bool sw = (gphid < 0.0) && (alpha * pow(-gphid, s_ph) > dlt * pow(th0, s_th));
+    bool armijo = ph <= ph0 + eta_ph * alpha * gphid;
+    bool ok;
+    if (th0 <= theta_min && sw) ok = armijo;
+    else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
+    if (!ok) continue;
+    if (!(sw && armijo)) {
+      if (nfilt == FILTER_MAX) {
+        for (int f = 0; f + 1 < FILTER_MAX; f++) {
+          W.filt[(size_t)(2 * f) * W.Bp + b] = W.filt[(size_t)(2 * f + 2) * W.Bp + b];
+          W.filt[(size_t)(2 * f + 1) * W.Bp + b] = W.filt[(size_t)(2 * f + 3) * W.Bp + b];
+        }
+        nfilt--;
+      }
+      W.filt[(size_t)(2 * nfilt) * W.Bp + b] = (1.0 - g_th) * th0;
+      W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * th0;
+      nfilt++;
+    }
+    accepted = true;
+    break;
+  }
+  bool take = true;
+  if (!accepted) {
+    STI(SI_NLSFAIL) += 1;
+    double fr = STD(ST_FORCE_REG);
+    if (fr < 1e4) {
+      STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 : fr * 100.0;
+      take = false;
+    } else {
+      nfilt = 0;
+      alpha = a_pri * pow(0.5, (double)(n_ls - 1));
+    }
+  }
+  if (take) {
+    STD(ST_FORCE_REG) = 0.0;
+    int nt = alpha <= 1e-3 ? STI(SI_NTINY) + 1 : 0;
+    STI(SI_NTINY) = nt;
+    if (o.stall_iter > 0 && nt >= o.stall_iter) {
+      STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+      take = false;
+    }
+  }
+  STD(ST_ALPHA) = take ? alpha : 0.0, STD(ST_ADUA) = a_dua;
+  STI(SI_STEP) = take ? 1 : 0;
+  STI(SI_ITERS) += 1;
+  // table smoothing follows the barrier parameter with one iteration lag; the filter restarts when it changes
+  if (STD(ST_EPS_NEXT) != STD(ST_EPS)) {
+    STD(ST_EPS) = STD(ST_EPS_NEXT);
+    nfilt = 0, STD(ST_THETA0) = -1.0;
+  }
+  STI(SI_NFILT) = nfilt;
+}
+
+// ------------------------------------------------------------------------------------------ k_update
+__global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
+  const double mu = W.st[(size_t)ST_MU * W.Bp + b];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    PL(W.X, i, k + 1, N + 1) += alpha * PL(W.dX, i, k + 1, N + 1);
+    PL(W.C, i, k, N) += alpha * PL(W.dC, i, k, N);
+    double l1 = PL(W.L1, i, k, N), l2 = PL(W.L2, i, k, N);
+    PL(W.L1, i, k, N) = l1 + alpha * (PL(W.nL1, i, k, N) - l1);
+    PL(W.L2, i, k, N) = l2 + alpha * (PL(W.nL2, i, k, N) - l2);
+  }
+  PL(W.U, 0, k, N) += alpha * PL(W.dU, 0, k, N), PL(W.U, 1, k, N) += alpha * PL(W.dU, 1, k, N);
+  const int ni = K.bd.ni, nact = (k + 1 <= N - 1) ? ni : ni - 3;
+  for (int m = 0; m < nact; m++) {
+    double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
+    double nu = PL(W.NU, m, k, N) + a_dua * PL(W.dNU, m, k, N);
+    double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
+    PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ I/O helpers
+// row-major (B x 8) user buffer -> [8][Bp] planes
+__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+#pragma unroll
+  for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[(size_t)b * 8 + i];
+}
+__global__ void k_zero_uprev(Work W) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  W.uprev[b] = 0.0, W.uprev[(size_t)W.Bp + b] = 0.0;
+}
+// u0 = U[:,0,:] -> row-major (B x 2) and u_prev := u0 (do_mpc: _u_prev = last returned u0)
+__global__ void k_store_u0(Work W, double* __restrict__ u0_rm) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  const int N = W.N;
+  double a = PL(W.U, 0, 0, N), c = PL(W.U, 1, 0, N);
+  if (u0_rm) u0_rm[(size_t)b * 2] = a, u0_rm[(size_t)b * 2 + 1] = c;
+  W.uprev[b] = a, W.uprev[(size_t)W.Bp + b] = c;
+}
+
+// plant: classical RK4 with n_sub sub-steps, zero-order-hold input (do_mpc Simulator / CVODES stand-in)
+__global__ void k_plant(Consts K, int B, const double* __restrict__ x, const double* __restrict__ u, double dt,
+                        int n_sub, double* __restrict__ xn) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double y[8], uu[2] = {u[(size_t)b * 2], u[(size_t)b * 2 + 1]};
+#pragma unroll
+  for (int i = 0; i < 8; i++) y[i] = x[(size_t)b * 8 + i];
+  const double hs = dt / n_sub;
+  for (int s = 0; s < n_sub; s++) {
+    double k1[8], k2[8], k3[8], k4[8], z[8];
+    rhs_val(K.p, K.T, 0.0, y, uu, k1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + 0.5 * hs * k1[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + 0.5 * hs * k2[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k3);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + hs * k3[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] += hs / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = y[i];
+}
+
+__global__ void k_slip_forces(Consts K, int B, const double* __restrict__ x, double* __restrict__ alpha,
+                              double* __restrict__ Fy) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const ltompc_params& p = K.p;
+  const double* xb = x + (size_t)b * 8;
+  double af = atan2(xb[4] + p.length_f * xb[5], xb[3]) - xb[6];
+  double ar = atan2(xb[4] - p.length_r * xb[5], xb[3]);
+  double L = p.length_f + p.length_r;
+  double Fnf = p.length_r * p.mass * p.gravity / L, Fnr = p.length_f * p.mass * p.gravity / L;
+  alpha[(size_t)b * 2] = af, alpha[(size_t)b * 2 + 1] = ar;
+  Fy[(size_t)b * 2] = -Fnf * p.D_f * sin(p.C_f * atan(p.B_f * af));
+  Fy[(size_t)b * 2 + 1] = -Fnr * p.D_r * sin(p.C_r * atan(p.B_r * ar));
+}
+
+// test hooks: model derivatives at given points (thread = point)
+__global__ void k_test_model(Consts K, int n, double eps, const double* __restrict__ x, const double* __restrict__ lam,
+                             double* __restrict__ f, double* __restrict__ J, double* __restrict__ H,
+                             double* __restrict__ cval, double* __restrict__ cgrad, double* __restrict__ cH,
+                             double* __restrict__ gval, double* __restrict__ ggrad, double* __restrict__ gH) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double xx[8], ll[8], ff[8], JJ[48], HH[36];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xx[i] = x[(size_t)t * 8 + i], ll[i] = lam[(size_t)t * 8 + i];
+#pragma unroll
+  for (int i = 0; i < 36; i++) HH[i] = 0.0;
+  rhs_derivs(K.p, K.T, eps, xx, ff, JJ, ll, 1.0, HH);
+  for (int i = 0; i < 6; i++) f[(size_t)t * 8 + i] = ff[i];
+  f[(size_t)t * 8 + 6] = f[(size_t)t * 8 + 7] = 0.0;
+  for (int i = 0; i < 48; i++) J[(size_t)t * 64 + i] = JJ[i];
+  for (int i = 48; i < 64; i++) J[(size_t)t * 64 + i] = 0.0;
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) H[(size_t)t * 64 + i * 8 + j] = HH[sidx(i, j)];
+  for (int term = 0; term < 2; term++) {
+    double g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, Hc[36];
+    for (int i = 0; i < 36; i++) Hc[i] = 0.0;
+    cval[(size_t)t * 2 + term] = cost_eval(K.p, K.T, eps, xx, term == 1, g, Hc);
+    for (int i = 0; i < 8; i++) {
+      cgrad[((size_t)t * 2 + term) * 8 + i] = g[i];
+      for (int j = 0; j < 8; j++) cH[((size_t)t * 2 + term) * 64 + i * 8 + j] = Hc[sidx(i, j)];
+    }
+  }
+  double gv[3], gs[3], gn[3], gm[3], hss[3], hmm[3];
+  cons_eval(K.p, K.T, eps, xx, gv, gs, gn, gm, hss, hmm);
+  for (int q = 0; q < 3; q++) {
+    gval[(size_t)t * 3 + q] = gv[q];
+    for (int i = 0; i < 8; i++) ggrad[((size_t)t * 3 + q) * 8 + i] = 0.0;
+    ggrad[((size_t)t * 3 + q) * 8 + 0] = gs[q], ggrad[((size_t)t * 3 + q) * 8 + 1] = gn[q], ggrad[((size_t)t * 3 + q) * 8 + 2] = gm[q];
+    for (int i = 0; i < 64; i++) gH[((size_t)t * 3 + q) * 64 + i] = 0.0;
+    gH[((size_t)t * 3 + q) * 64 + 0] = hss[q], gH[((size_t)t * 3 + q) * 64 + 2 * 8 + 2] = hmm[q];
+  }
+}
+
+#undef STD
+#undef STI
+}  // namespace ltompc

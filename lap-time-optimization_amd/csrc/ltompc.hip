@@ -1,0 +1,447 @@
+// ltompc.hip — host side of libltompc.so: the C ABI of include/ltompc.h over the kernels of kernels.h.
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -shared ltompc.hip -o libltompc.so
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace ltompc;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+  g_err = msg;
+  return -1;
+}
+#define HIPCHECK(expr)                                                                         \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+constexpr int NKERN = 6;  // eval, riccati, expand, linesearch, pick, update
+
+}  // namespace
+
+struct ltompc_solver {
+  Consts K;
+  Work W;
+  int device = 0, N = 0, B = 0, Bp = 0, n_table = 0, max_iter = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::vector<void*> allocs;
+  double* d_tables = nullptr;
+  double* d_x0_rm = nullptr;   // staging, row-major B x 8
+  double* d_u0_rm = nullptr;   // staging, row-major B x 2
+  double* d_io = nullptr;      // staging for plant / slip forces
+  int* h_active = nullptr;     // pinned
+  bool cold_next = true;
+  int poll_every = 4;
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  std::vector<int> ev_kind;
+  double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0};
+  int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0};
+  int last_launches = 0, last_iterations = 0;
+
+  template <typename T>
+  int dalloc(T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(q, 0, n * sizeof(T), stream);
+    if (e != hipSuccess) return fail(std::string("hipMemset: ") + hipGetErrorString(e));
+    allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return 0;
+  }
+};
+
+namespace {
+
+void build_bounds(const ltompc_params& p, Bounds& b) {
+  std::memset(&b, 0, sizeof b);
+  for (int i = 0; i < NX; i++) {  // per state: lower, then upper (same order as the oracle)
+    if (p.x_lb[i] > -LTOMPC_NO_BOUND) b.xb_idx[b.n_xb] = i, b.xb_sgn[b.n_xb] = -1.0, b.xb_val[b.n_xb] = p.x_lb[i], b.n_xb++;
+    if (p.x_ub[i] < LTOMPC_NO_BOUND) b.xb_idx[b.n_xb] = i, b.xb_sgn[b.n_xb] = +1.0, b.xb_val[b.n_xb] = p.x_ub[i], b.n_xb++;
+  }
+  for (int i = 0; i < NU; i++) {
+    if (p.u_lb[i] > -LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = -1.0, b.ub_val[b.n_ub] = p.u_lb[i], b.n_ub++;
+    if (p.u_ub[i] < LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = +1.0, b.ub_val[b.n_ub] = p.u_ub[i], b.n_ub++;
+  }
+  b.ni = b.n_ub + 2 * b.n_xb + NNL;
+}
+
+struct Launcher {
+  ltompc_solver* h;
+  int launches = 0;
+  template <typename Kern, typename... Args>
+  int run(int kind, Kern kern, int threads_total, Args... args) {
+    dim3 block(64), grid((threads_total + 63) / 64);
+    if (h->profiling) {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail("hipEventCreate failed");
+      hipEventRecord(a, h->stream);
+      hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+      hipEventRecord(b, h->stream);
+      h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(kind);
+    } else {
+      hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+    }
+    launches++;
+    return 0;
+  }
+};
+
+int collect_profile(ltompc_solver* h) {
+  for (size_t i = 0; i < h->ev_kind.size(); i++) {
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+    h->ms_by_kernel[h->ev_kind[i]] += ms;
+    h->launches_by_kernel[h->ev_kind[i]] += 1;
+    hipEventDestroy(h->ev[2 * i]), hipEventDestroy(h->ev[2 * i + 1]);
+  }
+  h->ev.clear(), h->ev_kind.clear();
+  return 0;
+}
+
+// planes [F][NK][Bp] (device) -> batch-major B x NK x F (host)
+int planes_to_host(ltompc_solver* h, const double* dev, int F, int NK, double* out) {
+  if (!out) return 0;
+  std::vector<double> tmp((size_t)F * NK * h->Bp);
+  HIPCHECK(hipMemcpyAsync(tmp.data(), dev, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++)
+    for (int k = 0; k < NK; k++)
+      for (int f = 0; f < F; f++) out[((size_t)b * NK + k) * F + f] = tmp[((size_t)f * NK + k) * h->Bp + b];
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ltompc_last_error(void) { return g_err.c_str(); }
+const char* ltompc_version(void) { return "ltompc 0.1 (gfx950, fp64, thread-per-interval kernels)"; }
+
+void ltompc_default_params(ltompc_params* p) {
+  std::memset(p, 0, sizeof *p);
+  // data/vehicles/MX5.json as read by model.py:42-64; D_f, D_r keep the constructor default 1.0 (model.py:22,26)
+  p->mass = 1000.0, p->inertia_z = 1000.0, p->length_f = 1.5, p->length_r = 1.5, p->width = 2.3;
+  p->B_f = 10.0, p->C_f = 1.3, p->D_f = 1.0, p->B_r = 12.0, p->C_r = 1.2, p->D_r = 1.0;
+  p->C_m = 1000.0, p->Cr_0 = 0.01, p->Cr_2 = 0.0003, p->gravity = 9.81;
+  // controller.py:29,52-53; mpc.py:104
+  p->q_n = 0.5, p->q_mu = 3.0, p->q_vy = 1.0, p->q_v = 1.0, p->vref_scale = 0.6, p->q_B = 1e-2;
+  p->r_du[0] = p->r_du[1] = 1e-2;
+  // controller.py:79-103
+  for (int i = 0; i < NX; i++) p->x_lb[i] = -LTOMPC_NO_BOUND, p->x_ub[i] = LTOMPC_NO_BOUND;
+  const double pi = 3.14159265358979323846;
+  p->x_lb[0] = 0.0;
+  p->x_lb[2] = -pi * 0.5, p->x_ub[2] = pi * 0.5;
+  p->x_lb[3] = 0.0;
+  p->x_lb[6] = -pi / 4, p->x_ub[6] = pi / 4;
+  p->x_lb[7] = -1.0, p->x_ub[7] = 1.0;
+  p->u_lb[0] = -2 * pi / 4, p->u_ub[0] = 2 * pi / 4;
+  p->u_lb[1] = -1.0, p->u_ub[1] = 1.0;
+}
+
+void ltompc_default_options(ltompc_options* o) {
+  std::memset(o, 0, sizeof *o);
+  o->t_step = 0.1, o->tol = 1e-8, o->acceptable_tol = 1e-6, o->mu_init = 0.1, o->mu_min = 1e-9;
+  o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
+  o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
+  o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15;
+}
+
+int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
+                  int n_horizon, int batch, int device, ltompc_handle* out) {
+  if (!params || !options || !tables || !out) return fail("ltompc_create: null argument");
+  if (n_table < 4) return fail("ltompc_create: n_table must be >= 4");
+  if (n_horizon < 2 || n_horizon > 4096) return fail("ltompc_create: n_horizon out of range [2, 4096]");
+  if (batch < 1) return fail("ltompc_create: batch must be >= 1");
+  if (options->n_linesearch < 1 || options->n_linesearch > MAX_LS) return fail("ltompc_create: n_linesearch out of range");
+  if (!(options->t_step > 0)) return fail("ltompc_create: t_step must be positive");
+  for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
+    for (int i = 0; i < n_table; i++)
+      if (!std::isfinite(tables[(size_t)r * n_table + i])) return fail("ltompc_create: non-finite table entry");
+  for (int i = 1; i < n_table; i++)
+    if (!(tables[i] > tables[i - 1]) || !(tables[2 * (size_t)n_table + i] > tables[2 * (size_t)n_table + i - 1]))
+      return fail("ltompc_create: table grids must be strictly increasing");
+  int ndev = 0;
+  HIPCHECK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("ltompc_create: no such HIP device");
+  HIPCHECK(hipSetDevice(device));
+  auto* h = new ltompc_solver();
+  h->device = device, h->N = n_horizon, h->B = batch, h->Bp = (batch + 63) / 64 * 64, h->n_table = n_table;
+  h->max_iter = options->max_iter;
+  h->K.p = *params, h->K.o = *options;
+  build_bounds(*params, h->K.bd);
+  if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return fail("hipStreamCreate failed");
+  }
+  h->stream = h->own_stream;
+  const size_t N = h->N, Bp = h->Bp;
+  const int ni = h->K.bd.ni;
+  Work& W = h->W;
+  W.N = h->N, W.B = h->B, W.Bp = h->Bp;
+  int rc = 0;
+  rc |= h->dalloc(&h->d_tables, (size_t)LTOMPC_TABLE_ROWS * n_table);
+  rc |= h->dalloc(&W.X, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.C, 8 * N * Bp), rc |= h->dalloc(&W.U, 2 * N * Bp);
+  rc |= h->dalloc(&W.L1, 8 * N * Bp), rc |= h->dalloc(&W.L2, 8 * N * Bp);
+  rc |= h->dalloc(&W.T, ni * N * Bp), rc |= h->dalloc(&W.NU, ni * N * Bp);
+  rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.dC, 8 * N * Bp), rc |= h->dalloc(&W.dU, 2 * N * Bp);
+  rc |= h->dalloc(&W.nL1, 8 * N * Bp), rc |= h->dalloc(&W.nL2, 8 * N * Bp);
+  rc |= h->dalloc(&W.dT, ni * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
+  rc |= h->dalloc(&W.QP, (size_t)QP_NF * N * Bp), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
+  rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp);
+  rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp);
+  rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);
+  rc |= h->dalloc(&W.st, (size_t)ST_NF * Bp), rc |= h->dalloc(&W.filt, (size_t)2 * FILTER_MAX * Bp);
+  rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
+  rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
+  if (rc) {
+    ltompc_destroy(h);
+    return -1;
+  }
+  if (hipHostMalloc((void**)&h->h_active, sizeof(int) * 4) != hipSuccess) {
+    ltompc_destroy(h);
+    return fail("hipHostMalloc failed");
+  }
+  if (hipMemcpyAsync(h->d_tables, tables, sizeof(double) * LTOMPC_TABLE_ROWS * n_table, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess) {
+    ltompc_destroy(h);
+    return fail("table upload failed");
+  }
+  Tables& T = h->K.T;
+  T.n = n_table;
+  T.s_kappa = h->d_tables, T.kappa = h->d_tables + n_table, T.s_arc = h->d_tables + 2 * (size_t)n_table;
+  T.n_left = h->d_tables + 3 * (size_t)n_table, T.n_right = h->d_tables + 4 * (size_t)n_table, T.v_ref = h->d_tables + 5 * (size_t)n_table;
+  *out = h;
+  return 0;
+}
+
+int ltompc_destroy(ltompc_handle h) {
+  if (!h) return 0;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) hipFree(p);
+  if (h->h_active) hipHostFree(h->h_active);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+  return 0;
+}
+
+int ltompc_set_stream(ltompc_handle h, void* hip_stream) {
+  if (!h) return fail("null handle");
+  h->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : h->own_stream;
+  return 0;
+}
+
+int ltompc_set_profiling(ltompc_handle h, int on) {
+  if (!h) return fail("null handle");
+  h->profiling = on != 0;
+  for (int i = 0; i < NKERN; i++) h->ms_by_kernel[i] = 0, h->launches_by_kernel[i] = 0;
+  return 0;
+}
+
+int ltompc_set_poll_every(ltompc_handle h, int n) {
+  if (!h || n < 1) return fail("ltompc_set_poll_every: bad argument");
+  h->poll_every = n;
+  return 0;
+}
+
+int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev) {
+  if (!h || !x0_dev) return fail("ltompc_set_initial_guess: null argument");
+  HIPCHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
+  hipLaunchKernelGGL(k_zero_uprev, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W);
+  hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, 1);
+  HIPCHECK(hipGetLastError());
+  h->cold_next = true;  // the next make_step starts from this guess
+  return 0;
+}
+
+int ltompc_set_initial_guess(ltompc_handle h, const double* x0) {
+  if (!h || !x0) return fail("ltompc_set_initial_guess: null argument");
+  HIPCHECK(hipSetDevice(h->device));
+  HIPCHECK(hipMemcpyAsync(h->d_x0_rm, x0, sizeof(double) * 8 * h->B, hipMemcpyHostToDevice, h->stream));
+  int rc = ltompc_set_initial_guess_dev(h, h->d_x0_rm);
+  if (rc) return rc;
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) {
+  if (!h || !x0_dev) return fail("ltompc_make_step: null argument");
+  HIPCHECK(hipSetDevice(h->device));
+  const int B = h->B, N = h->N, Bp = h->Bp;
+  Launcher L{h};
+  hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
+  if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
+  hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, h->cold_next ? 1 : 0);
+  HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
+  h->cold_next = false;
+  int it = 0;
+  for (;; it++) {
+    if (L.run(0, k_eval, N * Bp, h->K, h->W)) return -1;
+    if (L.run(1, k_riccati, Bp, h->K, h->W, it)) return -1;
+    if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
+    if (L.run(2, k_expand, N * Bp, h->K, h->W)) return -1;
+    if (L.run(3, k_linesearch, N * Bp, h->K, h->W)) return -1;
+    if (L.run(4, k_pick, Bp, h->K, h->W)) return -1;
+    if (L.run(5, k_update, N * Bp, h->K, h->W)) return -1;
+    if ((it + 1) % h->poll_every == 0) {
+      HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      if (h->h_active[0] == 0) break;  // every instance terminated in k_riccati of iteration `it` or earlier
+    }
+  }
+  hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev);
+  HIPCHECK(hipGetLastError());
+  h->last_launches = L.launches + 3;
+  h->last_iterations = it + 1;
+  if (h->profiling) {
+    HIPCHECK(hipStreamSynchronize(h->stream));
+    if (collect_profile(h)) return -1;
+  }
+  return 0;
+}
+
+int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error, double* objective, double* mu) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  std::vector<int> si((size_t)SI_NF * h->Bp);
+  std::vector<double> st((size_t)ST_NF * h->Bp);
+  HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(st.data(), h->W.st, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++) {
+    if (status) status[b] = si[(size_t)SI_STATUS * h->Bp + b];
+    if (iters) iters[b] = si[(size_t)SI_ITERS * h->Bp + b];
+    if (kkt_error) kkt_error[b] = st[(size_t)ST_E0 * h->Bp + b];
+    if (objective) objective[b] = st[(size_t)ST_OBJ * h->Bp + b];
+    if (mu) mu[b] = st[(size_t)ST_MU * h->Bp + b];
+  }
+  return 0;
+}
+
+int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  std::vector<int> si((size_t)SI_NF * h->Bp);
+  HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++) {
+    if (n_reg) n_reg[b] = si[(size_t)SI_NREG * h->Bp + b];
+    if (n_lsfail) n_lsfail[b] = si[(size_t)SI_NLSFAIL * h->Bp + b];
+  }
+  return 0;
+}
+
+int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status, int* iters) {
+  if (!h || !x0 || !u0) return fail("ltompc_make_step: null argument");
+  HIPCHECK(hipSetDevice(h->device));
+  for (size_t i = 0; i < (size_t)8 * h->B; i++)
+    if (!std::isfinite(x0[i])) return fail("ltompc_make_step: non-finite x0");
+  HIPCHECK(hipMemcpyAsync(h->d_x0_rm, x0, sizeof(double) * 8 * h->B, hipMemcpyHostToDevice, h->stream));
+  int rc = ltompc_make_step_dev(h, h->d_x0_rm, h->d_u0_rm);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(u0, h->d_u0_rm, sizeof(double) * 2 * h->B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  if (status || iters) return ltompc_get_stats(h, status, iters, nullptr, nullptr, nullptr);
+  return 0;
+}
+
+int ltompc_get_prediction(ltompc_handle h, double* X, double* U) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  if (planes_to_host(h, h->W.X, 8, h->N + 1, X)) return -1;
+  return planes_to_host(h, h->W.U, 2, h->N, U);
+}
+
+int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double* L1, double* L2) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  if (planes_to_host(h, h->W.X, 8, h->N + 1, X)) return -1;
+  if (planes_to_host(h, h->W.C, 8, h->N, C)) return -1;
+  if (planes_to_host(h, h->W.U, 2, h->N, U)) return -1;
+  if (planes_to_host(h, h->W.L1, 8, h->N, L1)) return -1;
+  return planes_to_host(h, h->W.L2, 8, h->N, L2);
+}
+
+int ltompc_plant_step_dev(ltompc_handle h, const double* x_dev, const double* u_dev, int n_sub, double* x_next_dev) {
+  if (!h || !x_dev || !u_dev || !x_next_dev) return fail("ltompc_plant_step: null argument");
+  if (n_sub < 1) return fail("ltompc_plant_step: n_sub must be >= 1");
+  HIPCHECK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_plant, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->K, h->B, x_dev, u_dev, h->K.o.t_step, n_sub, x_next_dev);
+  HIPCHECK(hipGetLastError());
+  return 0;
+}
+
+int ltompc_plant_step(ltompc_handle h, const double* x, const double* u, int n_sub, double* x_next) {
+  if (!h || !x || !u || !x_next) return fail("ltompc_plant_step: null argument");
+  HIPCHECK(hipSetDevice(h->device));
+  double *dx = h->d_io, *du = h->d_io + 8 * (size_t)h->Bp, *dn = h->d_io + 10 * (size_t)h->Bp;
+  HIPCHECK(hipMemcpyAsync(dx, x, sizeof(double) * 8 * h->B, hipMemcpyHostToDevice, h->stream));
+  HIPCHECK(hipMemcpyAsync(du, u, sizeof(double) * 2 * h->B, hipMemcpyHostToDevice, h->stream));
+  int rc = ltompc_plant_step_dev(h, dx, du, n_sub, dn);
+  if (rc) return rc;
+  HIPCHECK(hipMemcpyAsync(x_next, dn, sizeof(double) * 8 * h->B, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ltompc_slip_forces(ltompc_handle h, const double* x, int batch, double* alpha, double* Fy) {
+  if (!h || !x || !alpha || !Fy) return fail("ltompc_slip_forces: null argument");
+  if (batch < 1 || batch > h->B) return fail("ltompc_slip_forces: batch must be in [1, handle batch]");
+  HIPCHECK(hipSetDevice(h->device));
+  double *dx = h->d_io, *da = h->d_io + 8 * (size_t)h->Bp, *df = h->d_io + 10 * (size_t)h->Bp;
+  HIPCHECK(hipMemcpyAsync(dx, x, sizeof(double) * 8 * batch, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_slip_forces, dim3((batch + 63) / 64), dim3(64), 0, h->stream, h->K, batch, dx, da, df);
+  HIPCHECK(hipGetLastError());
+  HIPCHECK(hipMemcpyAsync(alpha, da, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(Fy, df, sizeof(double) * 2 * batch, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_kernel6, int* launches, int* ip_iterations) {
+  if (!h) return fail("null handle");
+  for (int i = 0; i < NKERN; i++) {
+    if (ms_by_kernel6) ms_by_kernel6[i] = h->ms_by_kernel[i];
+    if (launches_by_kernel6) launches_by_kernel6[i] = h->launches_by_kernel[i];
+  }
+  if (launches) *launches = h->last_launches;
+  if (ip_iterations) *ip_iterations = h->last_iterations;
+  return 0;
+}
+
+// Test hook: model derivatives at n points (host arrays): x, lam: n x 8 -> f: n x 8, J, H: n x 64 (row-major 8x8),
+// cost value/grad/Hessian for lterm and mterm (n x 2 [x 8 [x 8]]), constraints gL, gR+, gR- (n x 3 [x 8 [x 8]]).
+int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const double* lam, double* f, double* J,
+                      double* H, double* cval, double* cgrad, double* cH, double* gval, double* ggrad, double* gH) {
+  if (!h || n < 1) return fail("ltompc_test_model: bad argument");
+  HIPCHECK(hipSetDevice(h->device));
+  const size_t sizes[12] = {8, 8, 8, 64, 64, 2, 16, 128, 3, 24, 192, 0};
+  double* dev[11];
+  const double* src[2] = {x, lam};
+  double* dst[9] = {f, J, H, cval, cgrad, cH, gval, ggrad, gH};
+  for (int i = 0; i < 11; i++) HIPCHECK(hipMalloc((void**)&dev[i], sizeof(double) * sizes[i] * n));
+  for (int i = 0; i < 2; i++) HIPCHECK(hipMemcpy(dev[i], src[i], sizeof(double) * sizes[i] * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_model, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->K, n, eps, dev[0], dev[1], dev[2], dev[3],
+                     dev[4], dev[5], dev[6], dev[7], dev[8], dev[9], dev[10]);
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 9; i++) HIPCHECK(hipMemcpy(dst[i], dev[2 + i], sizeof(double) * sizes[2 + i] * n, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 11; i++) hipFree(dev[i]);
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""Host-side mirror of the reference's MPC interface (same names, argument meaning and error behaviour), over the GPU solver.
+
+    reference                                   here
+    ---------------------------------------     ------------------------------------------------
+    mpc.track.Track(veh, track, method, n)      Track(...)            src/mpc/track.py:11
+    mpc.model.VehicleModel(json, track)         VehicleModel(...)     src/mpc/model.py:12
+    mpc.controller.Controller(model, costs,     Controller(...)       src/mpc/controller.py:9
+        n_horizon=10, t_step=0.1, n_robust=0)
+    controller.mpc.x0 = x0                      same                  src/mpc.py:117
+    controller.mpc.set_initial_guess()          same                  src/mpc.py:118
+    u0 = controller.mpc.make_step(x0)           same, (8,1) -> (2,1)  src/mpc.py:142   <- the hot path
+    mpc.simulator.Simulator(model).simulator    same, make_step(u0)   src/mpc/simulator.py:14-20, mpc.py:143
+
+A counterpart of the reference's closed-loop driver (src/mpc.py:86-173) is `closed_loop()` below.
+"""
+from __future__ import annotations
+
+import json
+import os
+import re
+
+import numpy as np
+
+from . import _lib
+from .solver import BatchedMPC
+from .tables import TrackTables, build_tables, default_vehicle_json, _DATA
+
+
+class Track:
+    """Look-up tables of one (vehicle, track, method) race line (src/mpc/track.py:11-42)."""
+
+    def __init__(self, vehicle_name="MX-5", track_name="buckmore", method_name="curvature", n_samples=846,
+                 data_dir: str | None = None):
+        # the reference resolves <cwd>/data/plots/<vehicle>/<track>/<method> (mpc/track.py:12-13); the one race line
+        # it can actually run on ships with this package
+        if data_dir is None:
+            key = f"{track_name}_{vehicle_name.lower().replace('-', '')}_{method_name}"
+            data_dir = os.path.join(_DATA, "tracks", key)
+        if not os.path.isdir(data_dir):
+            raise FileNotFoundError(data_dir)
+        self.n_samples = n_samples
+        self.tables: TrackTables = build_tables(data_dir, n_samples)
+
+
+class VehicleModel:
+    """Vehicle parameters (src/mpc/model.py:12-64).  Same loader semantics: JSON with // and /* */ comments,
+    reads exactly the keys the reference reads; D_f, D_r are NOT read and stay 1.0."""
+
+    def __init__(self, params_file_path: str | None, track: Track):
+        self.track = track
+        self.params = _lib.default_params()
+        self.load_params(params_file_path or default_vehicle_json())
+
+    @staticmethod
+    def remove_comments(json_str: str) -> str:
+        json_str = re.sub(r"//.*", "", json_str)
+        return re.sub(r"/\*.*?\*/", "", json_str, flags=re.DOTALL)
+
+    def load_params(self, path: str):
+        with open(path) as f:
+            data = json.loads(self.remove_comments(f.read()))
+        p = self.params
+        p.inertia_z = data["rotational_inertia"]
+        self.name = data["name"]
+        p.mass = data["mass"]
+        p.length_f, p.length_r, p.width = data["length_f"], data["length_r"], data["width"]
+        p.B_f, p.C_f = data["frontTire"]["B_f"], data["frontTire"]["C_f"]
+        p.B_r, p.C_r = data["rearTire"]["B_r"], data["rearTire"]["C_r"]
+        p.C_m = data["control"]["C_m"]
+        p.Cr_0, p.Cr_2 = data["Cr_0"], data["Cr_2"]
+        self.ptv = data["ptv"]  # read and unused, like the reference (Mtv = 0, model.py:164)
+
+
+class _MPC:
+    """The subset of do_mpc.controller.MPC that src/mpc.py touches."""
+
+    def __init__(self, solver: BatchedMPC):
+        self._solver = solver
+        self._x0 = None
+        self._guess_set = False
+
+    @property
+    def x0(self):
+        return self._x0
+
+    @x0.setter
+    def x0(self, val):
+        val = np.asarray(val, dtype=np.float64)
+        if val.size != 8 * self._solver.B:
+            raise AssertionError(f"x0 must have {8 * self._solver.B} elements, got shape {val.shape}")
+        self._x0 = val.reshape(self._solver.B, 8).copy()
+
+    def set_initial_guess(self):
+        if self._x0 is None:
+            raise AssertionError("set mpc.x0 before set_initial_guess()")
+        self._solver.set_initial_guess(self._x0)
+        self._guess_set = True
+
+    def make_step(self, x0):
+        x0 = np.asarray(x0, dtype=np.float64)
+        single = x0.shape == (8, 1) or x0.shape == (8,)
+        if not self._guess_set:  # do_mpc warns and uses its default guess; here: all slots = x0, like set_initial_guess
+            self._x0 = x0.reshape(self._solver.B, 8).copy()
+            self.set_initial_guess()
+        u0 = self._solver.make_step(x0.reshape(self._solver.B, 8))
+        self.solver_stats = dict(status=self._solver.status.copy(), iters=self._solver.iters.copy())
+        return u0.reshape(2, 1) if single else u0
+
+
+class Controller:
+    """src/mpc/controller.py:9-34: NLP weights, bounds and IPOPT settings; builds the device solver."""
+
+    def __init__(self, model: VehicleModel, control_costs, n_horizon: int = 10, t_step: float = 0.1, n_robust: int = 0,
+                 batch: int = 1, device: int = 0, options=None):
+        control_costs = np.asarray(control_costs, dtype=np.float64)
+        assert control_costs.shape == (2, 1)  # controller.py:38
+        if n_robust != 0:
+            raise NotImplementedError("multi-stage robust MPC is disabled in the reference (n_robust=0)")
+        self.model = model
+        self.t_step = t_step
+        p = model.params
+        p.r_du[0], p.r_du[1] = float(control_costs[0, 0]), float(control_costs[1, 0])
+        p.q_n, p.q_mu, p.q_B = 0.5, 3.0, 1e-2  # controller.py:29
+        o = options or _lib.default_options()
+        o.t_step = t_step
+        self.solver = BatchedMPC(model.track.tables, n_horizon=n_horizon, batch=batch, params=p, options=o, device=device)
+        self.mpc = _MPC(self.solver)
+
+
+class _Sim:
+    def __init__(self, solver: BatchedMPC, n_sub: int):
+        self._solver, self._n_sub, self.x0 = solver, n_sub, None
+
+    def make_step(self, u0):
+        u0 = np.asarray(u0, dtype=np.float64)
+        single = u0.shape == (2, 1)
+        x = np.asarray(self.x0, dtype=np.float64).reshape(self._solver.B, 8)
+        xn = self._solver.plant_step(x, u0.reshape(self._solver.B, 2), self._n_sub)
+        self.x0 = xn.reshape(8, 1) if single else xn
+        return self.x0
+
+
+class Simulator:
+    """src/mpc/simulator.py:14-20: plant with t_step = 0.1 (plotting part of the reference is out of scope)."""
+
+    def __init__(self, controller: Controller, n_sub: int = 400):
+        self.simulator = _Sim(controller.solver, n_sub)
+
+
+def closed_loop(controller: Controller, x0, steps: int, out_json: str | None = None):
+    """Counterpart of the reference's loop (src/mpc.py:117-159): make_step -> plant -> identity estimator.
+    Returns dict(x, y, u, Fy, alpha) with the reference's sim_results.json schema."""
+    x0 = np.reshape(np.asarray(x0, dtype=np.float64), (-1, 1))
+    sim = Simulator(controller).simulator
+    sim.x0 = x0
+    controller.mpc.x0 = x0
+    controller.mpc.set_initial_guess()
+    X = np.zeros((steps + 1, 8, 1)); Y = np.zeros((steps + 1, 8, 1)); U = np.zeros((steps + 1, 2, 1))
+    Fys = np.zeros((steps + 1, 2)); alphas = np.zeros((steps + 1, 2))
+    X[0] = Y[0] = x0
+    for i in range(1, steps + 1):
+        u0 = controller.mpc.make_step(x0)
+        y = sim.make_step(u0)
+        x0 = y  # StateFeedback estimator is the identity (mpc.py:119-120,144)
+        X[i], Y[i], U[i] = x0, y, u0
+        a, F = controller.solver.slip_forces(x0.reshape(1, 8))
+        alphas[i], Fys[i] = a[0], F[0]
+    data = {"x": X.tolist(), "y": Y.tolist(), "u": U.tolist(), "Fy": Fys.tolist(), "alpha": alphas.tolist()}
+    if out_json:
+        with open(out_json, "w") as f:
+            json.dump(data, f)
+    return data

@@ -1,0 +1,128 @@
+"""BatchedMPC: thin Python owner of one ltompc handle (B independent MPC instances on one MI355X)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import NX, NU, Options, Params, check, dptr, iptr, lib
+from .tables import TrackTables
+
+
+class BatchedMPC:
+    """B receding-horizon NLPs of the reference's controller (src/mpc/controller.py:9-103), solved on the GPU.
+
+    make_step(x0 (B,8)) -> u0 (B,2): the batched form of `controller.mpc.make_step(x0)` (src/mpc.py:142).
+    """
+
+    def __init__(self, tables: TrackTables, n_horizon: int = 10, batch: int = 1, params: Params | None = None,
+                 options: Options | None = None, device: int = 0):
+        self.tables = tables
+        self.N, self.B = int(n_horizon), int(batch)
+        self.params = params or _lib.default_params()
+        self.options = options or _lib.default_options()
+        self._tab = tables.packed()
+        self._h = C.c_void_p()
+        check(lib().ltompc_create(C.byref(self.params), C.byref(self.options), dptr(self._tab), self._tab.shape[1],
+                                  self.N, self.B, int(device), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().ltompc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference surface, batched -------------------------------------------------------------
+    def set_initial_guess(self, x0):
+        x0 = self._x(x0)
+        check(lib().ltompc_set_initial_guess(self._h, dptr(x0)))
+
+    def make_step(self, x0):
+        x0 = self._x(x0)
+        u0 = np.empty((self.B, NU))
+        self.status = np.empty(self.B, dtype=np.int32)
+        self.iters = np.empty(self.B, dtype=np.int32)
+        check(lib().ltompc_make_step(self._h, dptr(x0), dptr(u0), iptr(self.status), iptr(self.iters)))
+        return u0
+
+    # ---- device-pointer variants (bench, closed loop on the GPU) --------------------------------
+    def set_stream(self, hip_stream: int | None):
+        check(lib().ltompc_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def set_initial_guess_dev(self, x0_ptr: int):
+        check(lib().ltompc_set_initial_guess_dev(self._h, C.c_void_p(x0_ptr)))
+
+    def make_step_dev(self, x0_ptr: int, u0_ptr: int):
+        check(lib().ltompc_make_step_dev(self._h, C.c_void_p(x0_ptr), C.c_void_p(u0_ptr)))
+
+    def plant_step_dev(self, x_ptr: int, u_ptr: int, xn_ptr: int, n_sub: int = 400):
+        check(lib().ltompc_plant_step_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(u_ptr), int(n_sub), C.c_void_p(xn_ptr)))
+
+    # ---- results --------------------------------------------------------------------------------
+    def prediction(self):
+        X, U = np.empty((self.B, self.N + 1, NX)), np.empty((self.B, self.N, NU))
+        check(lib().ltompc_get_prediction(self._h, dptr(X), dptr(U)))
+        return X, U
+
+    def iterate(self):
+        X, U = np.empty((self.B, self.N + 1, NX)), np.empty((self.B, self.N, NU))
+        Cc, L1, L2 = (np.empty((self.B, self.N, NX)) for _ in range(3))
+        check(lib().ltompc_get_iterate(self._h, dptr(X), dptr(Cc), dptr(U), dptr(L1), dptr(L2)))
+        return dict(X=X, C=Cc, U=U, L1=L1, L2=L2)
+
+    def stats(self):
+        st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+        kkt, obj, mu = np.empty(self.B), np.empty(self.B), np.empty(self.B)
+        check(lib().ltompc_get_stats(self._h, iptr(st), iptr(it), dptr(kkt), dptr(obj), dptr(mu)))
+        nr, nf = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
+        check(lib().ltompc_get_counters(self._h, iptr(nr), iptr(nf)))
+        return dict(status=st, iters=it, kkt=kkt, obj=obj, mu=mu, n_reg=nr, n_lsfail=nf)
+
+    def plant_step(self, x, u, n_sub: int = 400):
+        x, u = self._x(x), np.ascontiguousarray(np.asarray(u, float).reshape(self.B, NU))
+        xn = np.empty_like(x)
+        check(lib().ltompc_plant_step(self._h, dptr(x), dptr(u), int(n_sub), dptr(xn)))
+        return xn
+
+    def slip_forces(self, x):
+        x = np.ascontiguousarray(np.asarray(x, float).reshape(-1, NX))
+        a, F = np.empty((x.shape[0], 2)), np.empty((x.shape[0], 2))
+        check(lib().ltompc_slip_forces(self._h, dptr(x), x.shape[0], dptr(a), dptr(F)))
+        return a, F
+
+    def set_profiling(self, on: bool):
+        check(lib().ltompc_set_profiling(self._h, int(on)))
+
+    def set_poll_every(self, n: int):
+        check(lib().ltompc_set_poll_every(self._h, int(n)))
+
+    def timing(self):
+        ms, ln = np.zeros(6), np.zeros(6, dtype=np.int32)
+        launches, its = C.c_int(), C.c_int()
+        check(lib().ltompc_get_timing(self._h, dptr(ms), iptr(ln), C.byref(launches), C.byref(its)))
+        names = ("eval", "riccati", "expand", "linesearch", "pick", "update")
+        return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
+                    launches=launches.value, ip_iterations=its.value)
+
+    def test_model(self, x, lam, eps: float = 0.0):
+        x = np.ascontiguousarray(np.asarray(x, float).reshape(-1, NX))
+        lam = np.ascontiguousarray(np.asarray(lam, float).reshape(-1, NX))
+        n = x.shape[0]
+        out = dict(f=np.empty((n, 8)), J=np.empty((n, 8, 8)), H=np.empty((n, 8, 8)), cval=np.empty((n, 2)),
+                   cgrad=np.empty((n, 2, 8)), cH=np.empty((n, 2, 8, 8)), gval=np.empty((n, 3)),
+                   ggrad=np.empty((n, 3, 8)), gH=np.empty((n, 3, 8, 8)))
+        check(lib().ltompc_test_model(self._h, n, C.c_double(eps), dptr(x), dptr(lam),
+                                      *(dptr(out[k]) for k in ("f", "J", "H", "cval", "cgrad", "cH", "gval", "ggrad", "gH"))))
+        return out
+
+    def _x(self, x0):
+        x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1, NX))
+        if x0.shape[0] != self.B:
+            raise ValueError(f"expected {self.B} states of dimension {NX}, got array of shape {x0.shape}")
+        return x0

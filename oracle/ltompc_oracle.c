@@ -1104,9 +1104,10 @@ int oracle_rhs(const ltompc_params* p, const double* tab, int nt, const double* 
   return 0;
 }
 /* fx: 8x8 row-major d f_i / d x_j ; H: sum_i lam_i d2 f_i, 8x8 */
-int oracle_rhs_derivs(const ltompc_params* p, const double* tab, int nt, const double* x, const double* lam,
+int oracle_rhs_derivs(const ltompc_params* p, const double* tab, int nt, double eps, const double* x, const double* lam,
                       double* f, double* fx, double* H) {
   tables_t T = tables_view(tab, nt);
+  T.eps_s = eps;
   rhs_jets F;
   rhs_jet(p, &T, x, &F);
   memset(fx, 0, sizeof(double) * 64), memset(H, 0, sizeof(double) * 64);
@@ -1120,9 +1121,10 @@ int oracle_rhs_derivs(const ltompc_params* p, const double* tab, int nt, const d
   return 0;
 }
 /* cost value/gradient/Hessian at a node; cons: gL,gR value + gradients + Hessians (2x8, 2x64) */
-int oracle_cost_derivs(const ltompc_params* p, const double* tab, int nt, const double* x, int terminal,
+int oracle_cost_derivs(const ltompc_params* p, const double* tab, int nt, double eps, const double* x, int terminal,
                        double* val, double* grad, double* H) {
   tables_t T = tables_view(tab, nt);
+  T.eps_s = eps;
   jet c = cost_jet(p, &T, x, terminal);
   *val = c.v;
   for (int a = 0; a < NX; a++) {
@@ -1131,9 +1133,10 @@ int oracle_cost_derivs(const ltompc_params* p, const double* tab, int nt, const 
   }
   return 0;
 }
-int oracle_cons_derivs(const ltompc_params* p, const double* tab, int nt, const double* x, double* val,
+int oracle_cons_derivs(const ltompc_params* p, const double* tab, int nt, double eps, const double* x, double* val,
                        double* grad, double* H) {
   tables_t T = tables_view(tab, nt);
+  T.eps_s = eps;
   jet g[NNL];
   cons_jet(p, &T, x, g);
   for (int q = 0; q < NNL; q++) {

@@ -82,22 +82,22 @@ class Oracle:
         lib().oracle_rhs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(u), _p(f))
         return f
 
-    def rhs_derivs(self, x, lam):
+    def rhs_derivs(self, x, lam, eps=0.0):
         x = np.ascontiguousarray(x, float); lam = np.ascontiguousarray(lam, float)
         f, fx, H = np.zeros(8), np.zeros((8, 8)), np.zeros((8, 8))
-        lib().oracle_rhs_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(lam), _p(f), _p(fx), _p(H))
+        lib().oracle_rhs_derivs(C.byref(self.p), _p(self.tab), self.nt, C.c_double(eps), _p(x), _p(lam), _p(f), _p(fx), _p(H))
         return f, fx, H
 
-    def cost_derivs(self, x, terminal=False):
+    def cost_derivs(self, x, terminal=False, eps=0.0):
         x = np.ascontiguousarray(x, float)
         v = C.c_double(); g, H = np.zeros(8), np.zeros((8, 8))
-        lib().oracle_cost_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), int(terminal), C.byref(v), _p(g), _p(H))
+        lib().oracle_cost_derivs(C.byref(self.p), _p(self.tab), self.nt, C.c_double(eps), _p(x), int(terminal), C.byref(v), _p(g), _p(H))
         return v.value, g, H
 
-    def cons_derivs(self, x):
+    def cons_derivs(self, x, eps=0.0):
         x = np.ascontiguousarray(x, float)
         v, g, H = np.zeros(3), np.zeros((3, 8)), np.zeros((3, 8, 8))
-        lib().oracle_cons_derivs(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(v), _p(g), _p(H))
+        lib().oracle_cons_derivs(C.byref(self.p), _p(self.tab), self.nt, C.c_double(eps), _p(x), _p(v), _p(g), _p(H))
         return v, g, H
 
     def slip_forces(self, x):
