@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py — MPC solves/s of the batched make_step path on N MI355X (one process per GPU).
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N > 1 via torch.distributed.run)
+One "step" = one control tick of the reference's closed loop (src/mpc.py:140-153) for every instance of the
+batch: make_step (one NLP solve per instance, warm-started from the previous solution) followed by the plant
+step that produces the next x0.  Inputs are resident in HBM when the timed region starts.
+Workload: BASELINE.json's metric config — horizon N=40, 8192 instances per GPU sampled along buckmore
+(SURVEY.md §8d C3/C4), weak scaling (per-GPU batch fixed; instances are independent, no data-path collective).
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# Algorithmic bytes per (instance, interval, IP iteration), SURVEY.md §8(d): stage QP blocks written by the
+# evaluation kernel and read by the Riccati kernel (153 words), Riccati outputs (36), evaluation inputs (46).
+WORDS_QP, WORDS_RIC_OUT, WORDS_EVAL_IN = 153, 36, 46
+BYTES_PER_STAGE_ITER = 8 * (2 * WORDS_QP + WORDS_RIC_OUT + WORDS_EVAL_IN)  # 3104
+BYTES_BY_KERNEL = {  # share of the 3104 B each kernel class moves (algorithmic, not measured traffic)
+    "eval": 8 * (WORDS_QP + WORDS_EVAL_IN), "riccati": 8 * (WORDS_QP + WORDS_RIC_OUT),
+    "expand": 8 * (WORDS_EVAL_IN + WORDS_RIC_OUT), "linesearch": 8 * WORDS_EVAL_IN, "pick": 0, "update": 8 * 2 * WORDS_EVAL_IN,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
+    ap.add_argument("--horizon", type=int, default=40)
+    ap.add_argument("--max-iter", type=int, default=150, help="interior-point iteration budget per solve")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="instances solved by the CPU oracle for cpu_baseline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import ltompc
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    ltompc.build_library()
+    tables = ltompc.build_tables()  # buckmore / MX-5 / curvature race line (the only one the reference MPC runs on)
+    B, N = args.batch, args.horizon
+    opts = ltompc.default_options()
+    opts.max_iter = args.max_iter
+    mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
+    stream = torch.cuda.current_stream(dev)
+    mpc.set_stream(stream.cuda_stream)
+
+    x0_host = ltompc.sample_x0(tables, B, seed=ltompc.scenarios.SEED + rank)
+    x = torch.from_numpy(x0_host).to(dev)
+    xn = torch.empty_like(x)
+    u = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+
+    def tick():
+        nonlocal x, xn
+        mpc.make_step_dev(x.data_ptr(), u.data_ptr())
+        mpc.plant_step_dev(x.data_ptr(), u.data_ptr(), xn.data_ptr(), 400)
+        x, xn = xn, x
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    # ---- warm-up: cold start (do_mpc set_initial_guess) + W ticks, untimed
+    mpc.set_initial_guess_dev(x.data_ptr())
+    for _ in range(args.warmup):
+        tick()
+    torch.cuda.synchronize(dev)
+
+    # ---- timed region: exactly K ticks
+    mpc.set_profiling(not args.no_profile)
+    iters_sum, solved, ip_launch_iters = 0, 0, 0
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    per_tick = []
+    for _ in range(args.steps):
+        tick()
+        per_tick.append(mpc.timing()["ip_iterations"])
+    torch.cuda.synchronize(dev)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    st = mpc.stats()  # last tick
+    tm = mpc.timing()
+    mpc.set_profiling(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        agg = torch.tensor([float((st["status"] == 0).sum()), float(st["iters"].sum())], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        n_solved_last, iters_last = agg.tolist()
+    else:
+        n_solved_last, iters_last = float((st["status"] == 0).sum()), float(st["iters"].sum())
+
+    total_solves = B * world * args.steps
+    value = total_solves / elapsed
+
+    # ---- roofline of the dominant kernel (rank 0; HIP events on the launch stream, accumulated over the timed ticks)
+    roofline = None
+    if not args.no_profile and rank == 0:
+        ms, ln = tm["ms"], tm["launches_by_kernel"]
+        dom = max(ms, key=lambda k: ms[k])
+        avg_ms = ms[dom] / max(1, ln[dom])
+        # instances still iterating, averaged over launches (finished instances idle inside a launch)
+        active_per_launch = float(st["iters"].sum()) * args.steps / max(1, sum(per_tick))  # last tick's distribution
+        bytes_per_launch = active_per_launch * N * BYTES_BY_KERNEL[dom]
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "launches": ln}
+
+    # ---- batch = 1 latency (second handle, same stream), reported as an extra
+    extras = {}
+    if rank == 0:
+        m1 = ltompc.BatchedMPC(tables, n_horizon=N, batch=1, options=opts, device=local_rank)
+        m1.set_stream(stream.cuda_stream)
+        x1 = ltompc.X0_REFERENCE[None].copy()
+        m1.set_initial_guess(x1)
+        u1 = m1.make_step(x1)
+        x1 = m1.plant_step(x1, u1)
+        torch.cuda.synchronize(dev)
+        tb = time.perf_counter()
+        nb = 5
+        for _ in range(nb):
+            u1 = m1.make_step(x1)
+            x1 = m1.plant_step(x1, u1)
+        torch.cuda.synchronize(dev)
+        extras["batch1_solves_per_s"] = nb / (time.perf_counter() - tb)
+        extras["batch1_iters_last"] = int(m1.iters[0])
+        m1.close()
+
+    # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on the host cores, bounded sample
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        ncores = os.cpu_count() or 1
+        nthreads = min(ncores, 16)
+        S = min(args.cpu_sample, B)
+        oo = orc.default_options()
+        oo.max_iter = args.max_iter
+        O = orc.Oracle(tables.packed(), options=oo)
+        xs = x0_host[:S]
+        r = O.solve(xs, N, nthreads=nthreads)  # cold start, untimed (creates the warm start)
+        xs1 = O.plant_step(xs, r["u0"])
+        tc = time.perf_counter()
+        r2 = O.solve(xs1, N, uprev=r["u0"], warm=r, nthreads=nthreads)
+        tcpu = time.perf_counter() - tc
+        cpu = {"value": S / tcpu, "unit": "MPC solves/s", "cores": nthreads, "kind": "port",
+               "sample": f"{S} instances of the same batch, N={N}, one warm tick, OpenMP over instances "
+                         f"({nthreads} threads of {ncores} host cores), {tcpu:.1f}s wall; oracle/ltompc_oracle.c "
+                         "(do_mpc/IPOPT itself is not installable offline)",
+               "iters_mean": float(r2["iters"].mean()), "solved_frac": float((r2["status"] == 0).mean())}
+
+    if rank == 0:
+        out = {
+            "metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": value, "unit": "MPC solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"batch={B} per GPU x {world} GPU, horizon N={N}, closed-loop warm ticks "
+                                   f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
+                       "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol,
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "solved_frac_last_tick": n_solved_last / (B * world),
+            "ip_iters_mean_last_tick": iters_last / (B * world),
+            "ip_iterations_launched_per_tick": per_tick,
+            "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
+        }
+        print(json.dumps(out))
+    mpc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
