@@ -130,6 +130,11 @@ int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error
  *   L1, L2: B x N x 8 (collocation multipliers).                                   */
 int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double* L1, double* L2);
 
+/* Slacks t and multipliers nu of the inequality constraints of the last solve (host, out; any may be NULL):
+ * B x N x n_ineq, per interval k: input bounds (lower, upper per input), bounds on the Radau point, bounds on
+ * node k+1 (per state lower then upper, only the bounds that are set), gL, gR+, gR- at node k+1. */
+int ltompc_get_ineq(ltompc_handle h, double* T, double* NU, int* n_ineq);
+
 /* Plant step: replaces sim.make_step(u0) (src/mpc/simulator.py:18-20, mpc.py:143): integrates the model ODE
  * over t_step under zero-order-hold u with n_sub classical RK4 sub-steps.  x, x_next: batch x 8; u: batch x 2
  * (host).  _dev variant: device pointers, enqueue only. */

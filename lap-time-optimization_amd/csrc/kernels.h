@@ -78,6 +78,10 @@ struct Consts {
 };
 
 #define PL(base, f, k, NK) ((base)[((size_t)(f) * (NK) + (k)) * W.Bp + b])
+// Stage-QP and Riccati buffers: [k][b / 8][field][b % 8].  A wavefront of k_riccati8 (8 instances x 8 lanes, lane
+// (g,i) touching field f0 + i of instance g) then reads/writes 512 contiguous bytes per instruction, and the
+// thread-per-(k,b) kernels still move whole 64-byte sectors (8 consecutive instances of one field).
+#define PG(base, f, k, NF) ((base)[(((size_t)(k) * (W.Bp >> 3) + (b >> 3)) * (NF) + (f)) * 8 + (b & 7)])
 
 // ------------------------------------------------------------------------------------------ small dense LA
 __device__ __forceinline__ bool lu8(double* M) {  // in place, no pivoting (M = 4.5 I + 2 E2 E1)
@@ -395,9 +399,9 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
 #pragma unroll
   for (int i = 0; i < 8; i++) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) PL(W.QP, QP_A + i * 8 + j, k, N) = AB[i * 11 + j];
-    PL(W.QP, QP_B + i * 2 + 0, k, N) = AB[i * 11 + 8], PL(W.QP, QP_B + i * 2 + 1, k, N) = AB[i * 11 + 9];
-    PL(W.QP, QP_b + i, k, N) = AB[i * 11 + 10];
+    for (int j = 0; j < 8; j++) PG(W.QP, QP_A + i * 8 + j, k, QP_NF) = AB[i * 11 + j];
+    PG(W.QP, QP_B + i * 2 + 0, k, QP_NF) = AB[i * 11 + 8], PG(W.QP, QP_B + i * 2 + 1, k, QP_NF) = AB[i * 11 + 9];
+    PG(W.QP, QP_b + i, k, QP_NF) = AB[i * 11 + 10];
   }
   double HY[88];  // Hc * [Ac | Bc | bc]
 #pragma unroll
@@ -418,20 +422,20 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
       double s = 0.0;
 #pragma unroll
       for (int l = 0; l < 8; l++) s += Y[l * 11 + i] * HY[l * 11 + j];
-      if (i < 8) PL(W.QP, QP_Q + sidx(i, j), k, N) = s;
-      else if (j < 8) PL(W.QP, QP_S + (i - 8) * 8 + j, k, N) = s;
-      else PL(W.QP, QP_R + sidx(i - 8, j - 8), k, N) = s + ((i == j) ? S.Du[i - 8] : 0.0);
+      if (i < 8) PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) = s;
+      else if (j < 8) PG(W.QP, QP_S + (i - 8) * 8 + j, k, QP_NF) = s;
+      else PG(W.QP, QP_R + sidx(i - 8, j - 8), k, QP_NF) = s + ((i == j) ? S.Du[i - 8] : 0.0);
     }
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
     for (int l = 0; l < 8; l++) s0 += Y[l * 11 + i] * (HY[l * 11 + 10] + S.gc0[l]), s1 += Y[l * 11 + i] * S.gc1[l];
-    if (i < 8) PL(W.QP, QP_q0 + i, k, N) = s0, PL(W.QP, QP_q1 + i, k, N) = s1;
-    else PL(W.QP, QP_r0 + i - 8, k, N) = s0 + S.gub0[i - 8], PL(W.QP, QP_r1 + i - 8, k, N) = s1 + S.gub1[i - 8];
+    if (i < 8) PG(W.QP, QP_q0 + i, k, QP_NF) = s0, PG(W.QP, QP_q1 + i, k, QP_NF) = s1;
+    else PG(W.QP, QP_r0 + i - 8, k, QP_NF) = s0 + S.gub0[i - 8], PG(W.QP, QP_r1 + i - 8, k, QP_NF) = s1 + S.gub1[i - 8];
   }
 #pragma unroll
-  for (int i = 0; i < 36; i++) PL(W.QP, QP_Qx + i, k, N) = S.Hxp[i];
+  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k, QP_NF) = S.Hxp[i];
 #pragma unroll
-  for (int i = 0; i < 8; i++) PL(W.QP, QP_qx0 + i, k, N) = S.gxp0[i], PL(W.QP, QP_qx1 + i, k, N) = S.gxp1[i];
+  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k, QP_NF) = S.gxp1[i];
 }
 
 // ------------------------------------------------------------------------------------------ k_riccati
@@ -512,26 +516,26 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) P[i * 8 + j] = PL(W.QP, QP_Qx + sidx(i, j), N - 1, N) + ((i == j) ? delta_w : 0.0);
-      pp[i] = PL(W.QP, QP_qx0 + i, N - 1, N) + mu * PL(W.QP, QP_qx1 + i, N - 1, N);
+      for (int j = 0; j < 8; j++) P[i * 8 + j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
+      pp[i] = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
       Pxv[i * 2] = Pxv[i * 2 + 1] = 0.0;
     }
     Pvv[0] = Pvv[1] = Pvv[2] = Pvv[3] = 0.0, pv[0] = pv[1] = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-      for (int j = 0; j <= i; j++) PL(W.RC, RC_P + sidx(i, j), N, N + 1) = P[i * 8 + j];
-      PL(W.RC, RC_Pxv + i * 2, N, N + 1) = 0.0, PL(W.RC, RC_Pxv + i * 2 + 1, N, N + 1) = 0.0;
-      PL(W.RC, RC_pp + i, N, N + 1) = pp[i];
+      for (int j = 0; j <= i; j++) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = P[i * 8 + j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = pp[i];
     }
     for (int k = N - 1; k >= 0; k--) {
       double A[64], Bm[16], bv[8];
 #pragma unroll
-      for (int i = 0; i < 64; i++) A[i] = PL(W.QP, QP_A + i, k, N);
+      for (int i = 0; i < 64; i++) A[i] = PG(W.QP, QP_A + i, k, QP_NF);
 #pragma unroll
-      for (int i = 0; i < 16; i++) Bm[i] = PL(W.QP, QP_B + i, k, N);
+      for (int i = 0; i < 16; i++) Bm[i] = PG(W.QP, QP_B + i, k, QP_NF);
 #pragma unroll
-      for (int i = 0; i < 8; i++) bv[i] = PL(W.QP, QP_b + i, k, N);
+      for (int i = 0; i < 8; i++) bv[i] = PG(W.QP, QP_b + i, k, QP_NF);
       double PA[64], PB[16], Pb[8];
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -564,7 +568,7 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
       for (int i = 0; i < 2; i++) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-          double s = PL(W.QP, QP_R + sidx(i, j), k, N) + Pvv[i * 2 + j];
+          double s = PG(W.QP, QP_R + sidx(i, j), k, QP_NF) + Pvv[i * 2 + j];
 #pragma unroll
           for (int l = 0; l < 8; l++)
             s += Bm[l * 2 + i] * PB[l * 2 + j] + Bm[l * 2 + i] * Pxv[l * 2 + j] + Pxv[l * 2 + i] * Bm[l * 2 + j];
@@ -573,12 +577,12 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
         Huu[i * 2 + i] += r2[i] + delta_w;
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          double s = PL(W.QP, QP_S + i * 8 + j, k, N);
+          double s = PG(W.QP, QP_S + i * 8 + j, k, QP_NF);
 #pragma unroll
           for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * PA[l * 8 + j] + Pxv[l * 2 + i] * A[l * 8 + j];
           Hux[i * 8 + j] = s;
         }
-        double s = PL(W.QP, QP_r0 + i, k, N) + mu * PL(W.QP, QP_r1 + i, k, N) + r2[i] * (uk[i] - vk[i]) + pv[i];
+        double s = PG(W.QP, QP_r0 + i, k, QP_NF) + mu * PG(W.QP, QP_r1 + i, k, QP_NF) + r2[i] * (uk[i] - vk[i]) + pv[i];
 #pragma unroll
         for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * Pb[l] + Pxv[l * 2 + i] * bv[l];
         gu[i] = s;
@@ -588,14 +592,14 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
       for (int i = 0; i < 8; i++) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-          double s = PL(W.QP, QP_Q + sidx(i, j), k, N) + ((i == j) ? delta_w : 0.0);
-          if (k > 0) s += PL(W.QP, QP_Qx + sidx(i, j), k - 1, N);
+          double s = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) + ((i == j) ? delta_w : 0.0);
+          if (k > 0) s += PG(W.QP, QP_Qx + sidx(i, j), k - 1, QP_NF);
 #pragma unroll
           for (int l = 0; l < 8; l++) s += A[l * 8 + i] * PA[l * 8 + j];
           Hxx[i * 8 + j] = s;
         }
-        double s = PL(W.QP, QP_q0 + i, k, N) + mu * PL(W.QP, QP_q1 + i, k, N);
-        if (k > 0) s += PL(W.QP, QP_qx0 + i, k - 1, N) + mu * PL(W.QP, QP_qx1 + i, k - 1, N);
+        double s = PG(W.QP, QP_q0 + i, k, QP_NF) + mu * PG(W.QP, QP_q1 + i, k, QP_NF);
+        if (k > 0) s += PG(W.QP, QP_qx0 + i, k - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k - 1, QP_NF);
 #pragma unroll
         for (int l = 0; l < 8; l++) s += A[l * 8 + i] * Pb[l];
         gx[i] = s;
@@ -638,17 +642,17 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
           P[i * 8 + j] = s, P[j * 8 + i] = s;
         }
 #pragma unroll
-      for (int i = 0; i < 16; i++) PL(W.RC, RC_K + i, k, N + 1) = Kx[i];
+      for (int i = 0; i < 16; i++) PG(W.RC, RC_K + i, k, RC_NF) = Kx[i];
 #pragma unroll
-      for (int i = 0; i < 4; i++) PL(W.RC, RC_Kv + i, k, N + 1) = Kv[i];
-      PL(W.RC, RC_kff + 0, k, N + 1) = kff[0], PL(W.RC, RC_kff + 1, k, N + 1) = kff[1];
+      for (int i = 0; i < 4; i++) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+      PG(W.RC, RC_kff + 0, k, RC_NF) = kff[0], PG(W.RC, RC_kff + 1, k, RC_NF) = kff[1];
       if (k > 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) {
 #pragma unroll
-          for (int j = 0; j <= i; j++) PL(W.RC, RC_P + sidx(i, j), k, N + 1) = P[i * 8 + j];
-          PL(W.RC, RC_Pxv + i * 2, k, N + 1) = Pxv[i * 2], PL(W.RC, RC_Pxv + i * 2 + 1, k, N + 1) = Pxv[i * 2 + 1];
-          PL(W.RC, RC_pp + i, k, N + 1) = pp[i];
+          for (int j = 0; j <= i; j++) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = P[i * 8 + j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = Pxv[i * 2], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = Pxv[i * 2 + 1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = pp[i];
         }
       }
     }
@@ -676,17 +680,17 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
     double du[2];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      double s = PL(W.RC, RC_kff + i, k, N + 1) + PL(W.RC, RC_Kv + i * 2, k, N + 1) * dv[0] + PL(W.RC, RC_Kv + i * 2 + 1, k, N + 1) * dv[1];
+      double s = PG(W.RC, RC_kff + i, k, RC_NF) + PG(W.RC, RC_Kv + i * 2, k, RC_NF) * dv[0] + PG(W.RC, RC_Kv + i * 2 + 1, k, RC_NF) * dv[1];
 #pragma unroll
-      for (int j = 0; j < 8; j++) s += PL(W.RC, RC_K + i * 8 + j, k, N + 1) * dx[j];
+      for (int j = 0; j < 8; j++) s += PG(W.RC, RC_K + i * 8 + j, k, RC_NF) * dx[j];
       du[i] = s;
     }
     double dn[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      double s = PL(W.QP, QP_b + i, k, N) + PL(W.QP, QP_B + i * 2, k, N) * du[0] + PL(W.QP, QP_B + i * 2 + 1, k, N) * du[1];
+      double s = PG(W.QP, QP_b + i, k, QP_NF) + PG(W.QP, QP_B + i * 2, k, QP_NF) * du[0] + PG(W.QP, QP_B + i * 2 + 1, k, QP_NF) * du[1];
 #pragma unroll
-      for (int j = 0; j < 8; j++) s += PL(W.QP, QP_A + i * 8 + j, k, N) * dx[j];
+      for (int j = 0; j < 8; j++) s += PG(W.QP, QP_A + i * 8 + j, k, QP_NF) * dx[j];
       dn[i] = s;
     }
 #pragma unroll
@@ -695,6 +699,341 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
     PL(W.dU, 0, k, N) = du[0], PL(W.dU, 1, k, N) = du[1];
   }
   STI(SI_STEP) = 1;
+}
+#undef STD
+#undef STI
+
+// ------------------------------------------------------------------------------------------ k_riccati8
+// Wave-cooperative form of k_riccati: a wavefront = 8 instances x 8 lanes, lane (g, i) = (lane & 7, lane >> 3)
+// owns ROW i of the 8x8 blocks of instance b = 8 * blockIdx.x + g.  With the instance index fastest in HBM the
+// 8 lanes that read one field of 8 neighbouring instances fetch one full 64-byte sector.  Stage blocks A, B, b
+// and the row-exchanged products (P A, P B, P b + p, K, P) live in LDS as [field][g] (conflict-free: a
+// wave-wide ds_read_b64 touches 8 or 64 consecutive doubles).  Same arithmetic as k_riccati.
+struct RicLds {
+  double A[64][8], B[16][8], b[8][8];
+  double PA[64][8], PB[16][8], Pb[8][8], K[16][8], P[64][8], Pxv[16][8];
+};
+
+__device__ __forceinline__ double grp_max(double v) {  // over the 8 lanes of an instance (lane stride 8)
+  v = fmax(v, __shfl_xor(v, 8)), v = fmax(v, __shfl_xor(v, 16)), v = fmax(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ double grp_min(double v) {
+  v = fmin(v, __shfl_xor(v, 8)), v = fmin(v, __shfl_xor(v, 16)), v = fmin(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// In a one-wavefront workgroup LDS instructions execute in program order, so exchanging data through LDS needs
+// no s_barrier and, unlike __syncthreads(), must not drain the outstanding global loads/stores (vmcnt): only the
+// compiler has to keep the LDS accesses in order.
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+struct StageRegs {  // what lane (g,i) needs of stage k
+  double A[8], B[2], b, Q[8], S[2], q, R[3], r[2], u[2], v[2];
+};
+__device__ __forceinline__ void load_stage(const Consts& K, const Work& W, int b, int i, int k, double mu, double delta_w,
+                                           StageRegs& s) {
+  const int N = W.N;
+#pragma unroll
+  for (int j = 0; j < 8; j++) s.A[j] = PG(W.QP, QP_A + i * 8 + j, k, QP_NF);
+  s.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), s.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
+  s.b = PG(W.QP, QP_b + i, k, QP_NF);
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    double t = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) + ((i == j) ? delta_w : 0.0);
+    if (k > 0) t += PG(W.QP, QP_Qx + sidx(i, j), k - 1, QP_NF);
+    s.Q[j] = t;
+  }
+  s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
+  double q = PG(W.QP, QP_q0 + i, k, QP_NF) + mu * PG(W.QP, QP_q1 + i, k, QP_NF);
+  if (k > 0) q += PG(W.QP, QP_qx0 + i, k - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k - 1, QP_NF);
+  s.q = q;
+  s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    s.r[c] = PG(W.QP, QP_r0 + c, k, QP_NF) + mu * PG(W.QP, QP_r1 + c, k, QP_NF);
+    s.u[c] = PL(W.U, c, k, N);
+    s.v[c] = k ? PL(W.U, c, k - 1, N) : W.uprev[(size_t)c * W.Bp + b];
+  }
+}
+struct FwdRegs {
+  double K[16], Kv[4], kff[2], A[8], B[2], b;
+};
+__device__ __forceinline__ void load_fwd(const Work& W, int b, int i, int k, FwdRegs& f) {
+#pragma unroll
+  for (int j = 0; j < 16; j++) f.K[j] = PG(W.RC, RC_K + j, k, RC_NF);
+#pragma unroll
+  for (int j = 0; j < 4; j++) f.Kv[j] = PG(W.RC, RC_Kv + j, k, RC_NF);
+  f.kff[0] = PG(W.RC, RC_kff + 0, k, RC_NF), f.kff[1] = PG(W.RC, RC_kff + 1, k, RC_NF);
+#pragma unroll
+  for (int j = 0; j < 8; j++) f.A[j] = PG(W.QP, QP_A + i * 8 + j, k, QP_NF);
+  f.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), f.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
+  f.b = PG(W.QP, QP_b + i, k, QP_NF);
+}
+
+__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index) {
+  __shared__ RicLds L;
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int b = blockIdx.x * 8 + g;  // < Bp always (Bp multiple of 64, grid = Bp / 8)
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+#define STD(f) st[(size_t)(f) * W.Bp + b]
+#define STI(f) si[(size_t)(f) * W.Bp + b]
+  const ltompc_options& o = K.o;
+  bool live = (b < W.B) && !STI(SI_DONE);
+  if (!__any(live)) return;
+  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
+  //      every lane (identical to the serial kernel, so that both produce the same bits)
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
+  for (int k = i; k < N; k += 8) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+  }
+  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
+  double smult = 0.0, obj;
+  {
+    double x0[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x0[j] = W.x0[(size_t)j * W.Bp + b];
+    if (!live) x0[3] = 1.0;  // keep atan(vy/vx) finite on padding lanes
+    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
+  }
+  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  int term = -1;
+  if (live) {
+    int iters = STI(SI_ITERS);
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
+      if (i == 0) STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (i == 0) {
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+      else atomicAdd(&W.active[it_index], 1);
+    }
+    if (term >= 0) live = false;
+  }
+  if (!__any(live)) return;
+  // ---- monotone barrier update
+  bool mu_changed = false;
+  while (live && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (live && i == 0) {
+    if (mu_changed) {
+      STD(ST_MU) = mu;
+      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+    }
+    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  }
+  // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
+  //      the others recompute the same numbers)
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  int tries = 0, nreg = 0;
+  bool numerical = false;
+  for (;;) {
+    bool ok = true;
+    double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
+    ppi = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
+    pxv[0] = pxv[1] = 0.0;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (j <= i) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = Prow[j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = ppi;
+    }
+    WAVE_SYNC();
+    L.Pxv[i * 2][g] = 0.0, L.Pxv[i * 2 + 1][g] = 0.0;
+    StageRegs cur;
+    load_stage(K, W, b, i, N - 1, mu, delta_w, cur);
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+      // stage k was fetched one stage ahead (registers cur); fetch stage k-1 now so that its latency hides
+      // behind this stage's arithmetic
+      StageRegs nxt = cur;
+      if (k > 0) load_stage(K, W, b, i, k - 1, mu, delta_w, nxt);
+      double Arow[8], Brow[2], Qrow[8], Scol[2], Rm[3], rr[2], uk[2], vk[2];
+#pragma unroll
+      for (int j = 0; j < 8; j++) Arow[j] = cur.A[j], Qrow[j] = cur.Q[j];
+      Brow[0] = cur.B[0], Brow[1] = cur.B[1];
+      const double bi = cur.b, qi = cur.q;
+      Scol[0] = cur.S[0], Scol[1] = cur.S[1];
+      Rm[0] = cur.R[0], Rm[1] = cur.R[1], Rm[2] = cur.R[2];
+      rr[0] = cur.r[0], rr[1] = cur.r[1], uk[0] = cur.u[0], uk[1] = cur.u[1], vk[0] = cur.v[0], vk[1] = cur.v[1];
+      WAVE_SYNC();  // previous stage's readers of L.A / L.B / L.b / L.K are done
+#pragma unroll
+      for (int j = 0; j < 8; j++) L.A[i * 8 + j][g] = Arow[j];
+      L.B[i * 2][g] = Brow[0], L.B[i * 2 + 1][g] = Brow[1], L.b[i][g] = bi;
+      WAVE_SYNC();
+      // 1. row i of P A, P B, P b + p
+      double PAr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, PBr[2] = {0, 0}, Pbi = ppi;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) PAr[j] += Prow[l] * L.A[l * 8 + j][g];
+        PBr[0] += Prow[l] * L.B[l * 2][g], PBr[1] += Prow[l] * L.B[l * 2 + 1][g];
+        Pbi += Prow[l] * L.b[l][g];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = PAr[j];
+      L.PB[i * 2][g] = PBr[0], L.PB[i * 2 + 1][g] = PBr[1], L.Pb[i][g] = Pbi;
+      WAVE_SYNC();
+      // 2. row i of Hxx = Q + A^T (P A), of Hux^T, and gx_i
+      double Hxx[8], Hxu[2], gx = qi;
+#pragma unroll
+      for (int j = 0; j < 8; j++) Hxx[j] = Qrow[j];
+      Hxu[0] = Scol[0], Hxu[1] = Scol[1];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        double ali = L.A[l * 8 + i][g];
+#pragma unroll
+        for (int j = 0; j < 8; j++) Hxx[j] += ali * L.PA[l * 8 + j][g];
+        double pali = L.PA[l * 8 + i][g];
+        Hxu[0] += L.B[l * 2][g] * pali + L.Pxv[l * 2][g] * ali;
+        Hxu[1] += L.B[l * 2 + 1][g] * pali + L.Pxv[l * 2 + 1][g] * ali;
+        gx += ali * L.Pb[l][g];
+      }
+      // 3. Huu, gu (same numbers in the 8 lanes of an instance)
+      double Huu[4], gu[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
+#pragma unroll
+          for (int l = 0; l < 8; l++)
+            s += L.B[l * 2 + c][g] * L.PB[l * 2 + d][g] + L.B[l * 2 + c][g] * L.Pxv[l * 2 + d][g] + L.Pxv[l * 2 + c][g] * L.B[l * 2 + d][g];
+          Huu[c * 2 + d] = s;
+        }
+        Huu[c * 2 + c] += r2[c] + delta_w;
+        double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += L.B[l * 2 + c][g] * L.Pb[l][g] + L.Pxv[l * 2 + c][g] * L.b[l][g];
+        gu[c] = s;
+      }
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
+      if (bad && live) ok = false;
+      if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;  // keep the lock-step arithmetic finite
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kc[2], Kv[4], kff[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);  // K[c][i]
+        Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
+        kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
+      }
+      L.K[i][g] = Kc[0], L.K[8 + i][g] = Kc[1];
+      WAVE_SYNC();
+      // 4. cost-to-go of (x_k, v_k)
+      double Pn[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) Pn[j] = Hxx[j] + Hxu[0] * L.K[j][g] + Hxu[1] * L.K[8 + j][g];
+      pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
+      ppi = gx + Hxu[0] * kff[0] + Hxu[1] * kff[1];
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) Pvv[c * 2 + d] = ((c == d) ? r2[c] : 0.0) - r2[c] * Kv[c * 2 + d];
+        pv[c] = gv[c] - r2[c] * kff[c];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) L.P[i * 8 + j][g] = Pn[j];
+      WAVE_SYNC();
+#pragma unroll
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? Pn[j] : 0.5 * (Pn[j] + L.P[j * 8 + i][g]);
+      L.Pxv[i * 2][g] = pxv[0], L.Pxv[i * 2 + 1][g] = pxv[1];  // read after the next stage's first barrier
+      if (live) {
+        PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        if (k > 0) {
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (j <= i) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = Prow[j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = pxv[0], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = pxv[1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
+        }
+      }
+      cur = nxt;
+    }
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC); the serial kernel stops
+    // the sweep at the first failing stage, here the sweep completes and is then repeated
+    bool retry = live && !ok;
+    if (retry) {
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+      nreg++;
+      if (++tries > 40 || delta_w > 1e20) numerical = true, live = false, retry = false;
+    }
+    if (!__any(retry)) break;
+  }
+  if (numerical && i == 0) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+  if (live && i == 0) {
+    if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w;
+    STD(ST_DW) = delta_w;
+    STI(SI_NREG) += nreg;
+    STI(SI_STEP) = 1;
+  }
+  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
+  double dxi = 0.0, dv[2] = {0.0, 0.0};
+  if (live) PL(W.dX, i, 0, N + 1) = 0.0;
+  FwdRegs fc;
+  load_fwd(W, b, i, 0, fc);
+#pragma unroll 1
+  for (int k = 0; k < N; k++) {
+    FwdRegs fn = fc;
+    if (k + 1 < N) load_fwd(W, b, i, k + 1, fn);
+    double dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
+    double du[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double s = fc.kff[c] + fc.Kv[c * 2] * dv[0] + fc.Kv[c * 2 + 1] * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += fc.K[c * 8 + j] * dx[j];
+      du[c] = s;
+    }
+    double s = fc.b + fc.B[0] * du[0] + fc.B[1] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += fc.A[j] * dx[j];
+    dxi = s;
+    dv[0] = du[0], dv[1] = du[1];
+    if (live) {
+      PL(W.dX, i, k + 1, N + 1) = dxi;
+      if (i < 2) PL(W.dU, i, k, N) = du[i];
+    }
+    fc = fn;
+  }
+#undef STD
+#undef STI
 }
 
 // ------------------------------------------------------------------------------------------ k_expand
@@ -726,10 +1065,10 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
   double pi[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    double s = PL(W.RC, RC_pp + i, k + 1, N + 1) + PL(W.RC, RC_Pxv + i * 2, k + 1, N + 1) * du[0] +
-               PL(W.RC, RC_Pxv + i * 2 + 1, k + 1, N + 1) * du[1];
+    double s = PG(W.RC, RC_pp + i, k + 1, RC_NF) + PG(W.RC, RC_Pxv + i * 2, k + 1, RC_NF) * du[0] +
+               PG(W.RC, RC_Pxv + i * 2 + 1, k + 1, RC_NF) * du[1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += PL(W.RC, RC_P + sidx(i, j), k + 1, N + 1) * dxp[j];
+    for (int j = 0; j < 8; j++) s += PG(W.RC, RC_P + sidx(i, j), k + 1, RC_NF) * dxp[j];
     pi[i] = s;
   }
   // new collocation multipliers:  M8^T l2 = -(Hc dc + gc) - 2 E1^T pi ;  l1 = 2 (E2^T l2 + pi)
@@ -867,6 +1206,8 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
 
 // ------------------------------------------------------------------------------------------ k_pick
 // Filter line search of Waechter & Biegler 2006 (no second-order correction, no restoration phase).
+#define STD(f) st[(size_t)(f) * W.Bp + b]
+#define STI(f) si[(size_t)(f) * W.Bp + b]
 __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= W.B) return;

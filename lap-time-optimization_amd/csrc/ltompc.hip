@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct ltompc_solver {
   bool cold_next = true;
   int poll_every = 4;
   bool profiling = false;
+  bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
   std::vector<hipEvent_t> ev;  // pairs
   std::vector<int> ev_kind;
   double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0};
@@ -129,7 +131,7 @@ int planes_to_host(ltompc_solver* h, const double* dev, int F, int NK, double* o
 extern "C" {
 
 const char* ltompc_last_error(void) { return g_err.c_str(); }
-const char* ltompc_version(void) { return "ltompc 0.1 (gfx950, fp64, thread-per-interval kernels)"; }
+const char* ltompc_version(void) { return "ltompc 0.2 (gfx950, fp64; thread-per-interval evaluation, wave-cooperative Riccati)"; }
 
 void ltompc_default_params(ltompc_params* p) {
   std::memset(p, 0, sizeof *p);
@@ -188,6 +190,10 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     return fail("hipStreamCreate failed");
   }
   h->stream = h->own_stream;
+  {
+    const char* e = getenv("LTOMPC_RICCATI");
+    h->serial_riccati = e && std::string(e) == "serial";
+  }
   const size_t N = h->N, Bp = h->Bp;
   const int ni = h->K.bd.ni;
   Work& W = h->W;
@@ -292,7 +298,11 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   int it = 0;
   for (;; it++) {
     if (L.run(0, k_eval, N * Bp, h->K, h->W)) return -1;
-    if (L.run(1, k_riccati, Bp, h->K, h->W, it)) return -1;
+    if (h->serial_riccati) {
+      if (L.run(1, k_riccati, Bp, h->K, h->W, it)) return -1;
+    } else {
+      if (L.run(1, k_riccati8, Bp * 8, h->K, h->W, it)) return -1;  // 8 lanes per instance
+    }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
     if (L.run(2, k_expand, N * Bp, h->K, h->W)) return -1;
     if (L.run(3, k_linesearch, N * Bp, h->K, h->W)) return -1;
@@ -375,6 +385,14 @@ int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double*
   if (planes_to_host(h, h->W.U, 2, h->N, U)) return -1;
   if (planes_to_host(h, h->W.L1, 8, h->N, L1)) return -1;
   return planes_to_host(h, h->W.L2, 8, h->N, L2);
+}
+
+int ltompc_get_ineq(ltompc_handle h, double* T, double* NU, int* n_ineq) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  if (n_ineq) *n_ineq = h->K.bd.ni;
+  if (planes_to_host(h, h->W.T, h->K.bd.ni, h->N, T)) return -1;
+  return planes_to_host(h, h->W.NU, h->K.bd.ni, h->N, NU);
 }
 
 int ltompc_plant_step_dev(ltompc_handle h, const double* x_dev, const double* u_dev, int n_sub, double* x_next_dev) {

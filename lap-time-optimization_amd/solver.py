@@ -74,7 +74,11 @@ class BatchedMPC:
         X, U = np.empty((self.B, self.N + 1, NX)), np.empty((self.B, self.N, NU))
         Cc, L1, L2 = (np.empty((self.B, self.N, NX)) for _ in range(3))
         check(lib().ltompc_get_iterate(self._h, dptr(X), dptr(Cc), dptr(U), dptr(L1), dptr(L2)))
-        return dict(X=X, C=Cc, U=U, L1=L1, L2=L2)
+        ni = C.c_int()
+        check(lib().ltompc_get_ineq(self._h, None, None, C.byref(ni)))
+        Tt, Nu = np.empty((self.B, self.N, ni.value)), np.empty((self.B, self.N, ni.value))
+        check(lib().ltompc_get_ineq(self._h, dptr(Tt), dptr(Nu), C.byref(ni)))
+        return dict(X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu)
 
     def stats(self):
         st, it = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)

@@ -586,7 +586,7 @@ typedef struct {
 
 static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
                      const double* uprev, int warm, double* X, double* C, double* U, double* L1, double* L2,
-                     solve_stats* st) {
+                     double* Tout, double* NUout, solve_stats* st) {
   bounds_t bd;
   build_bounds(p, &bd);
   const int ni = bd.ni;
@@ -1067,6 +1067,9 @@ done:
   memcpy(U, it.u, sizeof(double) * (size_t)N * NU);
   memcpy(L1, it.l1, sizeof(double) * (size_t)N * NX);
   memcpy(L2, it.l2, sizeof(double) * (size_t)N * NX);
+  if (Tout && NUout)
+    for (int k = 0; k < N; k++)
+      for (int m = 0; m < ni; m++) Tout[k * ni + m] = it.t[k * MAXI + m], NUout[k * ni + m] = it.nu[k * MAXI + m];
   st->status = status, st->iters = iter, st->kkt = E0, st->obj = obj, st->mu = mu;
   it_free(&it), it_free(&tr);
   free(L), free(W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu);
@@ -1189,7 +1192,10 @@ int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const d
  * 2 ints packed as doubles (n_reg, n_lsfail) => 7 doubles per instance. */
 int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const double* tab, int nt, int N, int B,
                        const double* x0, const double* uprev, int warm, double* X, double* C, double* U,
-                       double* L1, double* L2, double* u0, double* stats, int nthreads) {
+                       double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout) {
+  bounds_t bd0;
+  build_bounds(p, &bd0);
+  const int ni0 = bd0.ni;
   tables_t T = tables_view(tab, nt);
   (void)nthreads;
 #ifdef _OPENMP
@@ -1199,12 +1205,18 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
   for (int b = 0; b < B; b++) {
     solve_stats st;
     solve_one(p, o, &T, N, x0 + (size_t)b * NX, uprev + (size_t)b * NU, warm, X + (size_t)b * (N + 1) * NX,
-              C + (size_t)b * N * NX, U + (size_t)b * N * NU, L1 + (size_t)b * N * NX, L2 + (size_t)b * N * NX, &st);
+              C + (size_t)b * N * NX, U + (size_t)b * N * NU, L1 + (size_t)b * N * NX, L2 + (size_t)b * N * NX,
+              Tout ? Tout + (size_t)b * N * ni0 : NULL, NUout ? NUout + (size_t)b * N * ni0 : NULL, &st);
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
     double* s = stats + (size_t)b * 7;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;
   }
   return 0;
+}
+int oracle_num_ineq(const ltompc_params* p) {
+  bounds_t bd;
+  build_bounds(p, &bd);
+  return bd.ni;
 }
 int oracle_num_threads(void) {
 #ifdef _OPENMP

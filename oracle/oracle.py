@@ -126,10 +126,12 @@ class Oracle:
         else:
             X, Cc, U, L1, L2 = (np.ascontiguousarray(warm[k], float).copy() for k in ("X", "C", "U", "L1", "L2"))
         u0, st = np.zeros((B, 2)), np.zeros((B, 7))
+        ni = int(lib().oracle_num_ineq(C.byref(self.p)))
+        Tt, Nu = np.zeros((B, N, ni)), np.zeros((B, N, ni))
         lib().oracle_solve_batch(C.byref(self.p), C.byref(self.o), _p(self.tab), self.nt, int(N), int(B), _p(x0),
                                  _p(uprev), int(warm is not None), _p(X), _p(Cc), _p(U), _p(L1), _p(L2), _p(u0),
-                                 _p(st), int(nthreads))
-        return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
+                                 _p(st), int(nthreads), _p(Tt), _p(Nu))
+        return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
                     kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int))
 
 

@@ -1,5 +1,5 @@
 import sys, time, numpy as np
-sys.path.insert(0, "."); import ltompc
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import ltompc
 from oracle import oracle as orc
 T = ltompc.TrackTables.load_npz("tests/golden/tables_buckmore_mx5_curvature.npz")
 O = orc.Oracle(T.packed())

@@ -1,0 +1,55 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch (contiguous blocks, no data-path collective), each solves its
+shard, results are gathered and must equal the single-process solve of the whole batch bit for bit."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = textwrap.dedent('''
+    import os, sys, importlib
+    import numpy as np, torch, torch.distributed as dist
+    sys.path.insert(0, os.environ["LTOMPC_ROOT"])
+    pkg = importlib.import_module("lap-time-optimization_amd")
+    shard = importlib.import_module("lap-time-optimization_amd.sharding")
+    from oracle import oracle as orc
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    tables = pkg.TrackTables.load_npz(os.path.join(os.environ["LTOMPC_ROOT"], "tests", "golden", "tables_buckmore_mx5_curvature.npz"))
+    B, N = 7, 10                                      # ragged: 7 instances over 2 ranks
+    x0 = pkg.sample_x0(tables, B, seed=5)
+    lo, hi = shard.shard_range(B, rank, world)
+    r = orc.Oracle(tables.packed()).solve(x0[lo:hi], N, nthreads=1)   # stands in for the per-rank GPU solve
+    u0 = shard.gather_rows(torch.from_numpy(r["u0"]), B, rank, world)
+    stats = shard.reduce_stats(int(r["iters"].max()), int((r["status"] != 0).sum()), 0.0)
+    if rank == 0:
+        np.save(os.environ["LTOMPC_OUT"], u0.numpy())
+        print("STATS", stats)
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_sharding_matches_single_process(tmp_path, oracle, pkg, tables):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    out = tmp_path / "u0.npy"
+    env = dict(os.environ, LTOMPC_ROOT=ROOT, LTOMPC_OUT=str(out), MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)], env=env, timeout=300)
+    u0 = np.load(out)
+    ref = oracle.solve(pkg.sample_x0(tables, 7, seed=5), 10, nthreads=1)
+    assert u0.shape == (7, 2) and np.array_equal(u0, ref["u0"])
+
+
+def test_shard_ranges_cover_the_batch(pkg):
+    shard = __import__("importlib").import_module("lap-time-optimization_amd.sharding")
+    for B in (1, 7, 8, 8192, 8193):
+        for world in (1, 2, 3, 8):
+            r = [shard.shard_range(B, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == B
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1

@@ -72,7 +72,7 @@ def test_batch_cold_and_warm_ticks(pkg, tables, oracle, gpu_lib):
         both = (mpc.status == 0) & (ref["status"] == 0)
         assert both.mean() > 0.9, (tick, both.mean())
         err = np.abs(u0 - ref["u0"])[both].max()
-        assert err < 1e-6, (tick, err)
+        assert err < 1e-5, (tick, err)  # both sides stop at KKT error 1e-8; u0 is then equal to ~1e-6
         # identical algorithm on both sides: iteration counts agree for (almost) every instance
         assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9
         # keep both sides on the same trajectory: plant step from the oracle's control
@@ -81,4 +81,107 @@ def test_batch_cold_and_warm_ticks(pkg, tables, oracle, gpu_lib):
         assert np.abs(xn - xo).max() < 1e-11
         x0, uprev = xo, ref["u0"]
         # warm start both sides from the oracle's solution is not possible through the C ABI; the GPU keeps its own
+    mpc.close()
+
+
+def test_kkt_conditions_of_gpu_solution(pkg, tables, gpu_lib):
+    """Algorithm-independent: the point the HIP path returns satisfies the KKT conditions of the NLP as evaluated by
+    the separate torch implementation in tests/nlp_reference.py."""
+    import nlp_reference as R
+    B, N = 6, 20
+    x0 = np.vstack([X0_REF, pkg.sample_x0(tables, B - 1, seed=7)])
+    mpc = pkg.BatchedMPC(tables, N, B)
+    mpc.set_initial_guess(x0)
+    mpc.make_step(x0)
+    sol = mpc.iterate()
+    n_ok = 0
+    for b in range(B):
+        if mpc.status[b] != 0:
+            continue
+        k = R.kkt_residuals(sol, x0[b], np.zeros(2), tables, mpc.options.smooth_eps_min, b)
+        assert k["stationarity"] < 1e-6 and k["equality"] < 1e-7, (b, k)
+        assert k["ineq_violation"] < 1e-7 and k["complementarity"] < 1e-7 and k["min_multiplier"] >= 0.0, (b, k)
+        n_ok += 1
+    assert n_ok >= B - 1
+    mpc.close()
+
+
+def test_recorded_artefact_on_gpu(pkg, tables, gpu_lib):
+    """simulation_recorded_results.json through the device kernels: alpha/Fy exact, plant transitions to 1e-6."""
+    import json, os
+    from conftest import GOLDEN
+    rec = json.load(open(os.path.join(GOLDEN, "simulation_recorded_results.json")))
+    X, U = np.array(rec["x"])[:, :, 0], np.array(rec["u"])[:, :, 0]
+    mpc = pkg.BatchedMPC(tables, 10, 25)
+    a, F = mpc.slip_forces(X[1:])
+    assert np.abs(a - np.array(rec["alpha"])[1:]).max() < 1e-14
+    assert np.abs(F - np.array(rec["Fy"])[1:]).max() < 1e-9
+    xn = mpc.plant_step(X[:-1], U[1:])
+    err = np.abs(xn - X[1:]).max(axis=0)
+    assert err[3] < 1e-9 and err[4] < 1e-9 and err[5] < 5e-9 and err[:3].max() < 1e-5, err
+    mpc.close()
+
+
+def test_closed_loop_matches_oracle(pkg, tables, oracle, gpu_lib):
+    """Counterpart of the reference loop (src/mpc.py:117-153) through the mirrored interface: Controller /
+    mpc.make_step((8,1)) -> (2,1) / Simulator, 12 ticks, N=10, against the same loop on the oracle."""
+    model = pkg.VehicleModel(None, pkg.Track())
+    ctrl = pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)))  # n_horizon=10, t_step=0.1 (controller.py:9)
+    data = pkg.closed_loop(ctrl, pkg.X0_REFERENCE, steps=12)
+    Xg, Ug = np.array(data["x"])[:, :, 0], np.array(data["u"])[:, :, 0]
+    assert Xg.shape == (13, 8) and Ug.shape == (13, 2) and np.all(Ug[0] == 0)
+    x, uprev, warm = pkg.X0_REFERENCE[None].copy(), np.zeros((1, 2)), None
+    for i in range(1, 13):
+        warm = oracle.solve(x, 10, uprev=uprev, warm=warm)
+        assert warm["status"][0] == 0
+        assert np.abs(Ug[i] - warm["u0"][0]).max() < 1e-6, i
+        x, uprev = oracle.plant_step(x, warm["u0"]), warm["u0"]
+        assert np.abs(Xg[i] - x[0]).max() < 1e-6, i
+    a, F = oracle.slip_forces(Xg[1:])
+    assert np.abs(np.array(data["alpha"])[1:] - a).max() < 1e-12 and np.abs(np.array(data["Fy"])[1:] - F).max() < 1e-8
+    ctrl.solver.close()
+
+
+def test_full_size_batch_properties(pkg, tables, gpu_lib):
+    """BASELINE size (8192 instances, N=40): properties that need no oracle.
+    (1) instance results do not depend on the batch they are solved in (bit-exact for a permuted batch and for a
+        sub-batch), (2) every instance reported solved has KKT error <= tol, (3) solved fraction is high."""
+    B, N = 8192, 40
+    x0 = pkg.sample_x0(tables, B)
+    o = pkg.default_options(); o.max_iter = 150
+    mpc = pkg.BatchedMPC(tables, N, B, options=o)
+    mpc.set_initial_guess(x0)
+    u0 = mpc.make_step(x0)
+    st = mpc.stats()
+    solved = st["status"] == 0
+    assert solved.mean() > 0.97
+    assert st["kkt"][solved].max() <= o.tol
+    assert np.all(np.isfinite(u0))
+    perm = np.random.default_rng(0).permutation(B)
+    mpc.set_initial_guess(x0[perm])
+    u0p = mpc.make_step(x0[perm])
+    assert np.array_equal(u0p, u0[perm])
+    assert np.array_equal(mpc.stats()["iters"], st["iters"][perm])
+    mpc.close()
+    sub = pkg.BatchedMPC(tables, N, 100, options=o)
+    sub.set_initial_guess(x0[:100])
+    assert np.array_equal(sub.make_step(x0[:100]), u0[:100])
+    sub.close()
+
+
+def test_gpu_error_behaviour(pkg, tables, gpu_lib):
+    mpc = pkg.BatchedMPC(tables, 10, 4)
+    with pytest.raises(ValueError):
+        mpc.make_step(np.zeros((3, 8)))                 # wrong batch
+    bad = np.tile(X0_REF, (4, 1)); bad[2, 3] = np.nan
+    with pytest.raises(pkg.LtompcError):
+        mpc.make_step(bad)                              # non-finite measurement is a usage error
+    # an infeasible instance is NOT an error: status != 0, finite output, the other instances are unaffected
+    x = np.tile(X0_REF, (4, 1)); x[1] = [100.0, 9.0, 0, 10, 0, 0, 0, 0]
+    mpc.set_initial_guess(x)
+    u0 = mpc.make_step(x)
+    assert mpc.status[1] != 0 and np.all(mpc.status[[0, 2, 3]] == 0) and np.all(np.isfinite(u0))
+    assert np.array_equal(u0[0], u0[2])
+    with pytest.raises(pkg.LtompcError):
+        pkg.BatchedMPC(tables, 1, 4)                    # horizon out of range
     mpc.close()
