@@ -148,7 +148,7 @@ def test_full_size_batch_properties(pkg, tables, gpu_lib):
         sub-batch), (2) every instance reported solved has KKT error <= tol, (3) solved fraction is high."""
     B, N = 8192, 40
     x0 = pkg.sample_x0(tables, B)
-    o = pkg.default_options(); o.max_iter = 150
+    o = pkg.default_options(); o.max_iter = 300   # cold start: p90 of the iteration count is ~100
     mpc = pkg.BatchedMPC(tables, N, B, options=o)
     mpc.set_initial_guess(x0)
     u0 = mpc.make_step(x0)
