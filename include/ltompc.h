@@ -80,6 +80,10 @@ typedef struct ltompc_options {
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
   int stall_iter;         /* stop (status STALLED) after this many consecutive steps with alpha <= 1e-3; 0 = off */
+  int max_ls_fail;        /* stop (status STALLED) after this many failed line searches in one solve; 0 = off.
+                             IPOPT would enter its restoration phase at the first one and, on a locally infeasible
+                             problem, end with 'restoration failed'                                       (8) */
+  int reserved;
 } ltompc_options;
 
 typedef struct ltompc_solver* ltompc_handle;

@@ -22,6 +22,7 @@
 namespace ltompc {
 
 constexpr int FILTER_MAX = 16;
+constexpr double DW_KEEP = 1e-5;  // regularisation below this is dropped to exactly 0
 constexpr int MAX_LS = 12;
 
 // fields of the stage-QP buffer written by k_eval and read by k_riccati
@@ -50,10 +51,13 @@ enum : int { SP_apri = 0, SP_adua, SP_gphid, SP_NF };
 // per-instance double state
 enum : int {
   ST_MU = 0, ST_EPS, ST_EPS_NEXT, ST_DW_LAST, ST_FORCE_REG, ST_ALPHA, ST_ADUA, ST_E0, ST_OBJ, ST_TAU,
-  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_NF
+  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY, ST_NF
 };
 // per-instance int state
-enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_NF };
+// SI_RETRY: the last Riccati sweep failed the inertia test; the next launch repeats it with ST_DW_TRY (no new
+// evaluation).  SI_SKIP_EVAL: the iterate did not move (failed line search), k_eval's output is still valid.
+enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
+             SI_SKIP_EVAL, SI_NF };
 
 struct Work {
   int N, B, Bp;
@@ -68,6 +72,12 @@ struct Work {
   double *filt;        // [2*FILTER_MAX][Bp]
   int *si;             // [SI_NF][Bp]
   int *active;         // [max_iter+2] number of unfinished instances after iteration i
+  // compaction of the unfinished instances: thread j of a launch works on instance act[j], j < nact[0] <= n_launch.
+  // The list is sorted (stable compaction), so while nothing has finished it is the identity and accesses coalesce.
+  const int* act;
+  const int* nact;
+  int n_launch, n_pad;  // n_pad = n_launch rounded up to a multiple of 64
+  int debug_extra_sweeps;
 };
 
 struct Consts {
@@ -127,6 +137,30 @@ __device__ __forceinline__ void lu8_solve_t(const double* M, double* v) {  // M^
 }
 __device__ __forceinline__ double sym_get(const double* H, int i, int j) { return H[sidx(i, j)]; }
 
+
+// Visits the inequalities of a slot in their storage order (input bounds, Radau-point bounds, node bounds; per
+// variable lower then upper, only the bounds that are set).  `f(m, kind, i, sg, val)` gets the running index m,
+// kind 0/1/2 = u / c / x+, and the variable index i as a value that is a compile-time constant after unrolling,
+// so that per-variable arrays stay in registers (a run-time index would force them into scratch memory).
+template <typename F>
+__device__ __forceinline__ int for_each_bound(const ltompc_params& p, F&& f) {
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    if (p.u_lb[i] > -LTOMPC_NO_BOUND) f(m++, 0, i, -1.0, p.u_lb[i]);
+    if (p.u_ub[i] < LTOMPC_NO_BOUND) f(m++, 0, i, 1.0, p.u_ub[i]);
+  }
+#pragma unroll
+  for (int kind = 1; kind <= 2; kind++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (p.x_lb[i] > -LTOMPC_NO_BOUND) f(m++, kind, i, -1.0, p.x_lb[i]);
+      if (p.x_ub[i] < LTOMPC_NO_BOUND) f(m++, kind, i, 1.0, p.x_ub[i]);
+    }
+  }
+  return m;  // index of the first track constraint
+}
+
 // ------------------------------------------------------------------------------------------ slot linearisation
 // Slot k owns (u_k, c_k, x_{k+1}) and the collocation equations of interval k in do_mpc's Radau-IIA(2) form
 //   G1 = h f(c,u) + 2 x_k - 1.5 c - 0.5 x+ = 0 ,  G2 = h f(x+,u) - 2 x_k + 4.5 c - 2.5 x+ = 0   
@@ -139,8 +173,10 @@ struct Slot {
   double dcd[8], dxd[8], dud[2];     // parts of grad_z L that do not involve the collocation multipliers
   double gcost[8];
   double gs[3], gn[3], gm[3];        // gradients of gL, gR+, gR-
-  double h[MAX_NI];
+  double gv[3];                      // values of gL, gR+, gR- at x_{k+1}
+  double rp_ineq, cmax, cmin, smult; // WITH_DUAL: max |h + t|, max / min t nu, sum |nu| over the slot's inequalities
   double cost;
+  int m_nl;                          // storage index of gL
   bool nl;
 };
 
@@ -184,45 +220,37 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   S.Du[0] = S.Du[1] = 0.0, S.gub0[0] = S.gub0[1] = 0.0, S.gub1[0] = S.gub1[1] = 0.0, S.dud[0] = S.dud[1] = 0.0;
   // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
   // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
-  const Bounds& bd = K.bd;
-  int m = 0;
-  for (int i = 0; i < bd.n_ub; i++, m++) {
-    int j = bd.ub_idx[i];
-    double sg = bd.ub_sgn[i];
-    double hv = bound_h(sg, bd.ub_val[i], S.u[j]);
-    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
-    S.h[m] = hv;
-    S.Du[j] += nu * it, S.gub0[j] += sg * nu * (hv + t) * it, S.gub1[j] += sg * it;
-    if (WITH_DUAL) S.dud[j] += sg * nu;
-  }
-  for (int i = 0; i < bd.n_xb; i++, m++) {
-    int j = bd.xb_idx[i];
-    double sg = bd.xb_sgn[i];
-    double hv = bound_h(sg, bd.xb_val[i], S.c[j]);
-    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
-    S.h[m] = hv;
-    S.Hc[sidx(j, j)] += nu * it, S.gc0[j] += sg * nu * (hv + t) * it, S.gc1[j] += sg * it;
-    if (WITH_DUAL) S.dcd[j] += sg * nu;
-  }
-  for (int i = 0; i < bd.n_xb; i++, m++) {
-    int j = bd.xb_idx[i];
-    double sg = bd.xb_sgn[i];
-    double hv = bound_h(sg, bd.xb_val[i], S.xp[j]);
-    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
-    S.h[m] = hv;
-    S.Hxp[sidx(j, j)] += nu * it, S.gxp0[j] += sg * nu * (hv + t) * it, S.gxp1[j] += sg * it;
-    if (WITH_DUAL) S.dxd[j] += sg * nu;
-  }
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0;
+  const int m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
+    const double hv = sg * (xv - val);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    const double Sg = nu * it, g0 = sg * nu * (hv + t) * it, g1 = sg * it;
+    if (kind == 0) {
+      S.Du[j] += Sg, S.gub0[j] += g0, S.gub1[j] += g1;
+      if (WITH_DUAL) S.dud[j] += sg * nu;
+    } else if (kind == 1) {
+      S.Hc[sidx(j, j)] += Sg, S.gc0[j] += g0, S.gc1[j] += g1;
+      if (WITH_DUAL) S.dcd[j] += sg * nu;
+    } else {
+      S.Hxp[sidx(j, j)] += Sg, S.gxp0[j] += g0, S.gxp1[j] += g1;
+      if (WITH_DUAL) S.dxd[j] += sg * nu;
+    }
+    if (WITH_DUAL) {
+      S.rp_ineq = fmax(S.rp_ineq, fabs(hv + t));
+      S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+    }
+  });
+  S.m_nl = m_nl;
   S.nl = (k + 1 <= N - 1);  // nl_cons are checked at nodes 1..N-1 (node 0 is data, node N is not checked)
   if (S.nl) {
-    double gv[3], hss[3], hmm[3];
-    cons_eval(K.p, K.T, eps, S.xp, gv, S.gs, S.gn, S.gm, hss, hmm);
+    double hss[3], hmm[3];
+    cons_eval(K.p, K.T, eps, S.xp, S.gv, S.gs, S.gn, S.gm, hss, hmm);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
-      int mm = m + q;
+      int mm = m_nl + q;
       double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N), it = 1.0 / t;
-      double Sg = nu * it, s0 = nu * (gv[q] + t) * it;
-      S.h[mm] = gv[q];
+      double Sg = nu * it, s0 = nu * (S.gv[q] + t) * it;
       double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
 #pragma unroll
       for (int a = 0; a < 3; a++) {
@@ -233,10 +261,14 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
       }
       S.Hxp[sidx(0, 0)] += nu * hss[q];
       S.Hxp[sidx(2, 2)] += nu * hmm[q];
+      if (WITH_DUAL) {
+        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
+        S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+      }
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < 3; q++) S.h[m + q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
+    for (int q = 0; q < 3; q++) S.gv[q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
   }
 }
 
@@ -320,15 +352,14 @@ __global__ void k_init(Consts K, Work W, int cold) {
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
   const double mu = K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
-  const Bounds& bd = K.bd;
-  int m = 0;
   auto put = [&](int mm, double hv) {
     double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
     PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
   };
-  for (int i = 0; i < bd.n_ub; i++, m++) put(m, bound_h(bd.ub_sgn[i], bd.ub_val[i], u[bd.ub_idx[i]]));
-  for (int i = 0; i < bd.n_xb; i++, m++) put(m, bound_h(bd.xb_sgn[i], bd.xb_val[i], c[bd.xb_idx[i]]));
-  for (int i = 0; i < bd.n_xb; i++, m++) put(m, bound_h(bd.xb_sgn[i], bd.xb_val[i], xp[bd.xb_idx[i]]));
+  const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
+    put(mm, sg * (xv - val));
+  });
   double gv[3] = {-1.0, -1.0, -1.0};
   if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
   for (int q = 0; q < 3; q++) put(m + q, gv[q]);
@@ -339,7 +370,7 @@ __global__ void k_init(Consts K, Work W, int cold) {
     st[(size_t)ST_ALPHA * W.Bp + b] = 0.0, st[(size_t)ST_ADUA * W.Bp + b] = 0.0;
     st[(size_t)ST_E0 * W.Bp + b] = 1e300, st[(size_t)ST_OBJ * W.Bp + b] = 0.0, st[(size_t)ST_TAU * W.Bp + b] = 0.99;
     st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
-    st[(size_t)ST_DW * W.Bp + b] = 0.0;
+    st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
     for (int i = 0; i < SI_NF; i++) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
   }
@@ -348,10 +379,12 @@ __global__ void k_init(Consts K, Work W, int cold) {
 // ------------------------------------------------------------------------------------------ k_eval
 __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = tid % W.Bp, k = tid / W.Bp;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
   const int N = W.N;
-  if (k >= N || b >= W.B) return;
+  if (k >= N || j >= W.nact[0]) return;
+  const int b = W.act[j];
   if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  if (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b]) return;  // blocks of the last launch are still valid
   const double hdt = K.o.t_step;
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   Slot S;
@@ -382,14 +415,8 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
       if (k + 1 < N) ru -= 2.0 * K.p.r_du[i] * (PL(W.U, i, k + 1, N) - S.u[i]);
       rd = fmax(rd, fabs(ru));
     }
-    double cmax = 0.0, cmin = 1e300;
-    int ni = K.bd.ni, nact = S.nl ? ni : ni - 3;
-    for (int m = 0; m < nact; m++) {
-      double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
-      rp = fmax(rp, fabs(S.h[m] + t));
-      cmax = fmax(cmax, t * nu), cmin = fmin(cmin, t * nu);
-      sm += fabs(nu);
-    }
+    rp = fmax(rp, S.rp_ineq), sm += S.smult;
+    const double cmax = S.cmax, cmin = S.cmin;
     PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
     PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
   }
@@ -442,8 +469,9 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
 // One thread per instance.  State of the recursion is (x_k, v_k = u_{k-1}) because do_mpc's rterm penalises
 // u_k - u_{k-1} (controller.py:40-41): stage cost r |u_k - v_k|^2, v_{k+1} = u_k.
 __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= W.B) return;
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W.nact[0]) return;
+  const int b = W.act[j];
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
@@ -507,6 +535,7 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
   double delta_w = STD(ST_FORCE_REG);
   const double dw_last = STD(ST_DW_LAST);
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
   int tries = 0;
   bool numerical = false;
   for (;;) {
@@ -670,7 +699,8 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
     STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
     return;
   }
-  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w;
+  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+  else if (dw_last <= DW_KEEP) STD(ST_DW_LAST) = 0.0;
   STD(ST_DW) = delta_w;
   // ---- forward rollout ----
   double dx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[2] = {0, 0};
@@ -739,27 +769,31 @@ struct StageRegs {  // what lane (g,i) needs of stage k
 __device__ __forceinline__ void load_stage(const Consts& K, const Work& W, int b, int i, int k, double mu, double delta_w,
                                            StageRegs& s) {
   const int N = W.N;
+  // branch-free: the node block of x_k lives in slot k-1; for k = 0 (x_0 is data) slot 0 is read and weighted by 0,
+  // so that all ~45 loads of a stage are issued back to back and waited for once
+  const int km = k > 0 ? k - 1 : 0;
+  const double wn = k > 0 ? 1.0 : 0.0;
+  double qa[8], qb[8];
 #pragma unroll
   for (int j = 0; j < 8; j++) s.A[j] = PG(W.QP, QP_A + i * 8 + j, k, QP_NF);
   s.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), s.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
   s.b = PG(W.QP, QP_b + i, k, QP_NF);
 #pragma unroll
-  for (int j = 0; j < 8; j++) {
-    double t = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) + ((i == j) ? delta_w : 0.0);
-    if (k > 0) t += PG(W.QP, QP_Qx + sidx(i, j), k - 1, QP_NF);
-    s.Q[j] = t;
-  }
+  for (int j = 0; j < 8; j++) qa[j] = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF), qb[j] = PG(W.QP, QP_Qx + sidx(i, j), km, QP_NF);
   s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
-  double q = PG(W.QP, QP_q0 + i, k, QP_NF) + mu * PG(W.QP, QP_q1 + i, k, QP_NF);
-  if (k > 0) q += PG(W.QP, QP_qx0 + i, k - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k - 1, QP_NF);
-  s.q = q;
+  const double q0 = PG(W.QP, QP_q0 + i, k, QP_NF), q1 = PG(W.QP, QP_q1 + i, k, QP_NF);
+  const double x0 = PG(W.QP, QP_qx0 + i, km, QP_NF), x1 = PG(W.QP, QP_qx1 + i, km, QP_NF);
   s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
+  const double r00 = PG(W.QP, QP_r0 + 0, k, QP_NF), r01 = PG(W.QP, QP_r0 + 1, k, QP_NF);
+  const double r10 = PG(W.QP, QP_r1 + 0, k, QP_NF), r11 = PG(W.QP, QP_r1 + 1, k, QP_NF);
+  s.u[0] = PL(W.U, 0, k, N), s.u[1] = PL(W.U, 1, k, N);
+  const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
+  const double p0 = W.uprev[b], p1 = W.uprev[(size_t)W.Bp + b];
 #pragma unroll
-  for (int c = 0; c < 2; c++) {
-    s.r[c] = PG(W.QP, QP_r0 + c, k, QP_NF) + mu * PG(W.QP, QP_r1 + c, k, QP_NF);
-    s.u[c] = PL(W.U, c, k, N);
-    s.v[c] = k ? PL(W.U, c, k - 1, N) : W.uprev[(size_t)c * W.Bp + b];
-  }
+  for (int j = 0; j < 8; j++) s.Q[j] = qa[j] + ((i == j) ? delta_w : 0.0) + wn * qb[j];
+  s.q = q0 + mu * q1 + wn * (x0 + mu * x1);
+  s.r[0] = r00 + mu * r10, s.r[1] = r01 + mu * r11;
+  s.v[0] = k > 0 ? v0 : p0, s.v[1] = k > 0 ? v1 : p1;
 }
 struct FwdRegs {
   double K[16], Kv[4], kff[2], A[8], B[2], b;
@@ -779,15 +813,21 @@ __device__ __forceinline__ void load_fwd(const Work& W, int b, int i, int k, Fwd
 __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index) {
   __shared__ RicLds L;
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int b = blockIdx.x * 8 + g;  // < Bp always (Bp multiple of 64, grid = Bp / 8)
+  const int jj = blockIdx.x * 8 + g;
+  const bool valid = jj < W.nact[0];
+  const int b = W.act[valid ? jj : 0];  // padding lanes shadow a real instance read-only
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
 #define STD(f) st[(size_t)(f) * W.Bp + b]
 #define STI(f) si[(size_t)(f) * W.Bp + b]
   const ltompc_options& o = K.o;
-  bool live = (b < W.B) && !STI(SI_DONE);
+  bool live = valid && !STI(SI_DONE);
   if (!__any(live)) return;
+  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
+  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
+  // than one sweep however hard the worst instance of the batch is.
+  const bool retry = live && STI(SI_RETRY);
   // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
   //      every lane (identical to the serial kernel, so that both produce the same bits)
   double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
@@ -812,7 +852,7 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
   double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
   double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
   int term = -1;
-  if (live) {
+  if (live && !retry) {
     int iters = STI(SI_ITERS);
     if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
     else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
@@ -825,20 +865,20 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
     if (i == 0) {
       STD(ST_E0) = E0, STD(ST_OBJ) = obj;
       if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
-      else atomicAdd(&W.active[it_index], 1);
     }
     if (term >= 0) live = false;
   }
+  if (live && i == 0) atomicAdd(&W.active[it_index], 1);
   if (!__any(live)) return;
   // ---- monotone barrier update
   bool mu_changed = false;
-  while (live && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
     mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
     mu_changed = true;
     rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
     Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
   }
-  if (live && i == 0) {
+  if (live && !retry && i == 0) {
     if (mu_changed) {
       STD(ST_MU) = mu;
       STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
@@ -851,9 +891,11 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
   double delta_w = STD(ST_FORCE_REG);
   const double dw_last = STD(ST_DW_LAST);
-  int tries = 0, nreg = 0;
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  int tries = 0;
+  if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
   bool numerical = false;
-  for (;;) {
+  {
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
 #pragma unroll
@@ -983,24 +1025,27 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
       }
       cur = nxt;
     }
-    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC); the serial kernel stops
-    // the sweep at the first failing stage, here the sweep completes and is then repeated
-    bool retry = live && !ok;
-    if (retry) {
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC), one attempt per launch
+    if (live && !ok) {
       if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
       else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
-      nreg++;
-      if (++tries > 40 || delta_w > 1e20) numerical = true, live = false, retry = false;
+      if (++tries > 40 || delta_w > 1e20) numerical = true;
+      if (i == 0) {
+        STI(SI_NREG) += 1;
+        STI(SI_STEP) = 0;
+        if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+        else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = delta_w;
+      }
+      live = false;
     }
-    if (!__any(retry)) break;
   }
-  if (numerical && i == 0) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
   if (live && i == 0) {
-    if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w;
+    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
     STD(ST_DW) = delta_w;
-    STI(SI_NREG) += nreg;
+    STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
     STI(SI_STEP) = 1;
   }
+  if (!__any(live)) return;
   // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
   double dxi = 0.0, dv[2] = {0.0, 0.0};
   if (live) PL(W.dX, i, 0, N + 1) = 0.0;
@@ -1039,10 +1084,11 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
 // ------------------------------------------------------------------------------------------ k_expand
 __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = tid % W.Bp, k = tid / W.Bp;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
   const int N = W.N;
-  if (k >= N || b >= W.B) return;
-  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  if (k >= N || j >= W.nact[0]) return;
+  const int b = W.act[j];
+  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
   const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
   Slot S;
@@ -1099,28 +1145,25 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
   }
 #pragma unroll
   for (int a = 0; a < 8; a++) gphid += S.gcost[a] * dxp[a];
-  const Bounds& bd = K.bd;
-  const int ni = bd.ni, nact = S.nl ? ni : ni - 3;
-  for (int m = 0; m < ni; m++) {
-    if (m >= nact) {
-      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
-      continue;
-    }
-    double gd;
-    if (m < bd.n_ub) gd = bd.ub_sgn[m] * du[bd.ub_idx[m]];
-    else if (m < bd.n_ub + bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub] * dc[bd.xb_idx[m - bd.n_ub]];
-    else if (m < bd.n_ub + 2 * bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub - bd.n_xb] * dxp[bd.xb_idx[m - bd.n_ub - bd.n_xb]];
-    else {
-      int q = m - bd.n_ub - 2 * bd.n_xb;
-      gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
-    }
+  auto slack_step = [&](int m, double hv, double gd) {
     double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
-    double dtt = -(S.h[m] + t) - gd;
+    double dtt = -(hv + t) - gd;
     double dn = (mu - nu * dtt) / t - nu;
     PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
     if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
     if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
     gphid -= mu * dtt / t;
+  };
+  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
+    const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
+    slack_step(m, sg * (xv - val), sg * dv);
+  });
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int m = S.m_nl + q;
+    if (S.nl) slack_step(m, S.gv[q], S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
+    else PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
   }
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
@@ -1130,10 +1173,11 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
 // LS plane layout: [3 * (n_ls + 1)][N][Bp] : theta, cost, sum log t per candidate.
 __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = tid % W.Bp, k = tid / W.Bp;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
   const int N = W.N;
-  if (k >= N || b >= W.B) return;
-  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  if (k >= N || j >= W.nact[0]) return;
+  const int b = W.act[j];
+  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   const double hdt = K.o.t_step;
   double a_pri = 1.0;
@@ -1152,8 +1196,6 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
     v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
     dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
   }
-  const Bounds& bd = K.bd;
-  const int ni = bd.ni;
   const bool nl = (k + 1 <= N - 1);
   const int n_ls = K.o.n_linesearch;
   double alpha = 0.0;
@@ -1176,19 +1218,11 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
 #pragma unroll
     for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
     double sl = 0.0;
-    int m = 0;
-    for (int i = 0; i < bd.n_ub; i++, m++) {
-      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
-      th += fabs(bound_h(bd.ub_sgn[i], bd.ub_val[i], tu[bd.ub_idx[i]]) + t), sl += log(t);
-    }
-    for (int i = 0; i < bd.n_xb; i++, m++) {
-      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
-      th += fabs(bound_h(bd.xb_sgn[i], bd.xb_val[i], tc[bd.xb_idx[i]]) + t), sl += log(t);
-    }
-    for (int i = 0; i < bd.n_xb; i++, m++) {
-      double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
-      th += fabs(bound_h(bd.xb_sgn[i], bd.xb_val[i], txp[bd.xb_idx[i]]) + t), sl += log(t);
-    }
+    const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
+      const double xv = kind == 0 ? tu[j] : (kind == 1 ? tc[j] : txp[j]);
+      const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+      th += fabs(sg * (xv - val) + t), sl += log(t);
+    });
     if (nl) {
       double gv[3];
       cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1198,7 +1232,6 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
         th += fabs(gv[q] + t), sl += log(t);
       }
     }
-    (void)ni;
     PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
     alpha = (l == 0) ? a_pri : 0.5 * alpha;
   }
@@ -1209,12 +1242,13 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
 #define STD(f) st[(size_t)(f) * W.Bp + b]
 #define STI(f) si[(size_t)(f) * W.Bp + b]
 __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= W.B) return;
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= W.nact[0]) return;
+  const int b = W.act[j];
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
-  if (STI(SI_DONE)) return;
+  if (STI(SI_DONE) || !STI(SI_STEP)) return;  // finished, or the Riccati sweep of this launch has to be repeated
   const ltompc_options& o = K.o;
   const double mu = STD(ST_MU);
   double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
@@ -1281,11 +1315,14 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
     accepted = true;
     break;
   }
-  bool take = true;
+  bool take = true, give_up = false;
   if (!accepted) {
-    STI(SI_NLSFAIL) += 1;
+    const int nf = STI(SI_NLSFAIL) + 1;
+    STI(SI_NLSFAIL) = nf;
     double fr = STD(ST_FORCE_REG);
-    if (fr < 1e4) {
+    if (o.max_ls_fail > 0 && nf >= o.max_ls_fail) {
+      give_up = true, take = false;
+    } else if (fr < 1e4) {
       STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 : fr * 100.0;
       take = false;
     } else {
@@ -1293,6 +1330,7 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
       alpha = a_pri * pow(0.5, (double)(n_ls - 1));
     }
   }
+  if (give_up) STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
   if (take) {
     STD(ST_FORCE_REG) = 0.0;
     int nt = alpha <= 1e-3 ? STI(SI_NTINY) + 1 : 0;
@@ -1304,21 +1342,25 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
   }
   STD(ST_ALPHA) = take ? alpha : 0.0, STD(ST_ADUA) = a_dua;
   STI(SI_STEP) = take ? 1 : 0;
-  STI(SI_ITERS) += 1;
+  if (!STI(SI_DONE)) STI(SI_ITERS) += 1;  // (a solve that stops here has completed `iters` iterations, like the oracle)
   // table smoothing follows the barrier parameter with one iteration lag; the filter restarts when it changes
+  bool eps_switched = false;
   if (STD(ST_EPS_NEXT) != STD(ST_EPS)) {
     STD(ST_EPS) = STD(ST_EPS_NEXT);
     nfilt = 0, STD(ST_THETA0) = -1.0;
+    eps_switched = true;
   }
   STI(SI_NFILT) = nfilt;
+  STI(SI_SKIP_EVAL) = (!take && !eps_switched) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
 }
 
 // ------------------------------------------------------------------------------------------ k_update
 __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = tid % W.Bp, k = tid / W.Bp;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
   const int N = W.N;
-  if (k >= N || b >= W.B) return;
+  if (k >= N || j >= W.nact[0]) return;
+  const int b = W.act[j];
   if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
   const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
   const double mu = W.st[(size_t)ST_MU * W.Bp + b];
@@ -1338,6 +1380,36 @@ __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
     double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
     PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
   }
+}
+
+// ------------------------------------------------------------------------------------------ compaction
+__global__ void k_act_identity(int* act, int* nact, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) act[b] = b;
+  if (b == 0) nact[0] = B;
+}
+// Stable compaction of the unfinished instances of `src[0..nsrc)` into `dst`; one workgroup of 1024 threads.
+__global__ void __launch_bounds__(1024) k_compact(const int* __restrict__ src, const int* __restrict__ nsrc_p,
+                                                   const int* __restrict__ done, int* __restrict__ dst, int* __restrict__ ndst) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, nsrc = nsrc_p[0];
+  const int chunk = (nsrc + 1023) / 1024, lo = t * chunk, hi = min(nsrc, lo + chunk);
+  int c = 0;
+  for (int j = lo; j < hi; j++) c += done[src[j]] ? 0 : 1;
+  cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+    int v = t >= off ? cnt[t - off] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int pos = cnt[t] - c;
+  for (int j = lo; j < hi; j++) {
+    int b = src[j];
+    if (!done[b]) dst[pos++] = b;
+  }
+  if (t == 1023) ndst[0] = cnt[1023];
 }
 
 // ------------------------------------------------------------------------------------------ I/O helpers

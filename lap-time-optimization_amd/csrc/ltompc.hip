@@ -43,9 +43,12 @@ struct ltompc_solver {
   double* d_u0_rm = nullptr;   // staging, row-major B x 2
   double* d_io = nullptr;      // staging for plant / slip forces
   int* h_active = nullptr;     // pinned
+  int *d_act[2] = {nullptr, nullptr}, *d_nact[2] = {nullptr, nullptr};  // ping-pong lists of unfinished instances
+  int last_compactions = 0;
   bool cold_next = true;
   int poll_every = 4;
   bool profiling = false;
+  bool compaction = true;       // LTOMPC_COMPACT=0 switches the re-packing of unfinished instances off
   bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
   std::vector<hipEvent_t> ev;  // pairs
   std::vector<int> ev_kind;
@@ -159,7 +162,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->t_step = 0.1, o->tol = 1e-8, o->acceptable_tol = 1e-6, o->mu_init = 0.1, o->mu_min = 1e-9;
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
-  o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15;
+  o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
@@ -193,6 +196,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   {
     const char* e = getenv("LTOMPC_RICCATI");
     h->serial_riccati = e && std::string(e) == "serial";
+    const char* c = getenv("LTOMPC_COMPACT");
+    h->compaction = !(c && std::string(c) == "0");
   }
   const size_t N = h->N, Bp = h->Bp;
   const int ni = h->K.bd.ni;
@@ -212,6 +217,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);
   rc |= h->dalloc(&W.st, (size_t)ST_NF * Bp), rc |= h->dalloc(&W.filt, (size_t)2 * FILTER_MAX * Bp);
   rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
+  rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
     ltompc_destroy(h);
@@ -295,23 +301,47 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
   h->cold_next = false;
+  // all instances unfinished: identity list
+  int cur = 0, n_launch = B;
+  hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_act[0], h->d_nact[0], B);
+  Work W = h->W;
+  {
+    const char* e = getenv("LTOMPC_DEBUG_SWEEPS");
+    W.debug_extra_sweeps = e ? atoi(e) : 0;
+  }
+  auto set_launch = [&](int n) {
+    n_launch = n;
+    W.act = h->d_act[cur], W.nact = h->d_nact[cur], W.n_launch = n, W.n_pad = (n + 63) / 64 * 64;
+  };
+  set_launch(B);
+  h->last_compactions = 0;
   int it = 0;
   for (;; it++) {
-    if (L.run(0, k_eval, N * Bp, h->K, h->W)) return -1;
+    const int np = W.n_pad;
+    if (L.run(0, k_eval, N * np, h->K, W)) return -1;
     if (h->serial_riccati) {
-      if (L.run(1, k_riccati, Bp, h->K, h->W, it)) return -1;
+      if (L.run(1, k_riccati, np, h->K, W, it)) return -1;
     } else {
-      if (L.run(1, k_riccati8, Bp * 8, h->K, h->W, it)) return -1;  // 8 lanes per instance
+      if (L.run(1, k_riccati8, np * 8, h->K, W, it)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (L.run(2, k_expand, N * Bp, h->K, h->W)) return -1;
-    if (L.run(3, k_linesearch, N * Bp, h->K, h->W)) return -1;
-    if (L.run(4, k_pick, Bp, h->K, h->W)) return -1;
-    if (L.run(5, k_update, N * Bp, h->K, h->W)) return -1;
+    if (L.run(2, k_expand, N * np, h->K, W)) return -1;
+    if (L.run(3, k_linesearch, N * np, h->K, W)) return -1;
+    if (L.run(4, k_pick, np, h->K, W)) return -1;
+    if (L.run(5, k_update, N * np, h->K, W)) return -1;
     if ((it + 1) % h->poll_every == 0) {
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
-      if (h->h_active[0] == 0) break;  // every instance terminated in k_riccati of iteration `it` or earlier
+      const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
+      if (n_active == 0) break;
+      if (h->compaction && n_active <= (3 * n_launch) / 4) {
+        // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack the list
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
+                           h->W.si + (size_t)SI_DONE * Bp, h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+        cur ^= 1;
+        set_launch(n_active);  // upper bound of the compacted count; kernels test against the device-side count
+        h->last_compactions++;
+      }
     }
   }
   hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev);

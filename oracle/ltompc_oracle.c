@@ -583,6 +583,7 @@ typedef struct {
 } solve_stats;
 
 #define FILTER_MAX 64
+#define DW_KEEP 1e-5
 
 static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
                      const double* uprev, int warm, double* X, double* C, double* U, double* L1, double* L2,
@@ -792,6 +793,11 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
 
     /* ---- Riccati sweep on the state (x_k, v_k = u_{k-1}); retried with Hessian regularisation ---- */
     double delta_w = force_reg;
+    /* Deviation from IPOPT's Algorithm IC: while the previous iteration needed a regularisation larger than
+     * DW_KEEP the first attempt already uses delta_w_last / 3 instead of 0 (every attempt is a full sweep here;
+     * this halves the number of sweeps at the same iteration counts).  delta_w decays by 3 per iteration and
+     * returns to exactly 0 below DW_KEEP, so the final Newton iterations are unregularised. */
+    if (delta_w == 0.0 && delta_w_last > DW_KEEP) delta_w = delta_w_last / 3.0;
     int tries = 0;
     for (;;) {
       int ok = 1;
@@ -880,6 +886,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       if (++tries > 40 || delta_w > 1e20) { status = LTOMPC_STATUS_NUMERICAL; goto done; }
     }
     if (delta_w > 0) delta_w_last = delta_w;
+    if (delta_w_last <= DW_KEEP) delta_w_last = 0.0;
 
     /* ---- forward sweep + recovery of dc and the collocation multipliers ---- */
     memset(dx, 0, sizeof(double) * NX);
@@ -1030,6 +1037,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       /* no restoration phase here: retry this iterate with a (larger) forced regularisation; after a few
        * failures take the smallest step and reset the filter so that the iteration cannot stall */
       st->n_lsfail++;
+      if (o->max_ls_fail > 0 && st->n_lsfail >= o->max_ls_fail) { status = LTOMPC_STATUS_STALLED; break; }
       if (force_reg < 1e4) { force_reg = force_reg == 0 ? 1e-2 : force_reg * 100; continue; }
       nfilt = 0;
       alpha = a_pri * pow(0.5, o->n_linesearch - 1);
@@ -1098,7 +1106,7 @@ void oracle_default_options(ltompc_options* o) {
   memset(o, 0, sizeof *o);
   o->t_step = 0.1, o->tol = 1e-8, o->acceptable_tol = 1e-6, o->mu_init = 0.1, o->mu_min = 1e-9;
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
-  o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15;
+  o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
 }
 
 int oracle_rhs(const ltompc_params* p, const double* tab, int nt, const double* x, const double* u, double* f) {
