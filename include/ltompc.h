@@ -164,6 +164,10 @@ int ltompc_set_profiling(ltompc_handle h, int on);
 int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_kernel6, int* launches,
                       int* ip_iterations);
 
+/* Poll history of the last make_step: up to `capacity` triples (iteration, unfinished instances, launch width);
+ * returns the number of polls (>= 0). */
+int ltompc_get_history(ltompc_handle h, int* triples, int capacity);
+
 /* make_step polls the device's count of unfinished instances every n interior-point iterations (default 4). */
 int ltompc_set_poll_every(ltompc_handle h, int n);
 

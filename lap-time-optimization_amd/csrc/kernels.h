@@ -54,10 +54,11 @@ enum : int {
   ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY, ST_NF
 };
 // per-instance int state
+// SI_LSMORE: the full step was rejected by the filter test, the remaining step candidates have to be evaluated.
 // SI_RETRY: the last Riccati sweep failed the inertia test; the next launch repeats it with ST_DW_TRY (no new
 // evaluation).  SI_SKIP_EVAL: the iterate did not move (failed line search), k_eval's output is still valid.
 enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
-             SI_SKIP_EVAL, SI_NF };
+             SI_SKIP_EVAL, SI_LSMORE, SI_NF };
 
 struct Work {
   int N, B, Bp;
@@ -77,6 +78,7 @@ struct Work {
   const int* act;
   const int* nact;
   int n_launch, n_pad;  // n_pad = n_launch rounded up to a multiple of 64
+  int *ls_list, *ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
   int debug_extra_sweeps;
 };
 
@@ -748,6 +750,10 @@ __device__ __forceinline__ double grp_max(double v) {  // over the 8 lanes of an
   v = fmax(v, __shfl_xor(v, 8)), v = fmax(v, __shfl_xor(v, 16)), v = fmax(v, __shfl_xor(v, 32));
   return v;
 }
+__device__ __forceinline__ double grp_sum(double v) {
+  v += __shfl_xor(v, 8), v += __shfl_xor(v, 16), v += __shfl_xor(v, 32);
+  return v;
+}
 __device__ __forceinline__ double grp_min(double v) {
   v = fmin(v, __shfl_xor(v, 8)), v = fmin(v, __shfl_xor(v, 16)), v = fmin(v, __shfl_xor(v, 32));
   return v;
@@ -1171,69 +1177,78 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
 // ------------------------------------------------------------------------------------------ k_linesearch
 // candidate 0 is the current point (alpha = 0); candidate l >= 1 has alpha = a_pri * 2^-(l-1).
 // LS plane layout: [3 * (n_ls + 1)][N][Bp] : theta, cost, sum log t per candidate.
-__global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = tid % W.n_pad, k = tid / W.n_pad;
+// Two phases (97% of all iterations accept the full step): phase 0 evaluates the current point and the first candidate
+// for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
+__global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, int jw) {
+  // phase 0: thread = (k, j), evaluates the current point and the first candidate of instance act[j].
+  // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
+  //          list of rejected instances; jw = launch width in instances, longer lists are covered grid-stride.
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = W.N;
-  if (k >= N || j >= W.nact[0]) return;
-  const int b = W.act[j];
-  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
-  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
-  const double hdt = K.o.t_step;
-  double a_pri = 1.0;
-  for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
-  double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
-    dxk[i] = PL(W.dX, i, k, N + 1);
-    xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
-    c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
-    v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
-    dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
-  }
-  const bool nl = (k + 1 <= N - 1);
+  const int j0 = tid % jw, rest = tid / jw, k = rest % N, cand = rest / N;
   const int n_ls = K.o.n_linesearch;
-  double alpha = 0.0;
-  for (int l = 0; l <= n_ls; l++) {
-    double txk[8], txp[8], tc[8], tu[2], tv[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
-#pragma unroll
-    for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
-    double f1[8], f2[8];
-    rhs_val(K.p, K.T, eps, tc, tu, f1);
-    rhs_val(K.p, K.T, eps, txp, tu, f2);
-    double th = 0.0;
+  if (phase == 0 ? (rest >= N) : (cand >= n_ls - 1)) return;
+  const int count = phase == 0 ? W.nact[0] : W.ls_count[0];
+  const double hdt = K.o.t_step;
+  for (int j = j0; j < count; j += jw) {
+    const int b = phase == 0 ? W.act[j] : W.ls_list[j];
+    if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) continue;  // no step this launch
+    const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+    double a_pri = 1.0;
+    for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
+    double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
-      th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
+      xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+      dxk[i] = PL(W.dX, i, k, N + 1);
+      xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+      c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
     }
-    double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
 #pragma unroll
-    for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
-    double sl = 0.0;
-    const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
-      const double xv = kind == 0 ? tu[j] : (kind == 1 ? tc[j] : txp[j]);
-      const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
-      th += fabs(sg * (xv - val) + t), sl += log(t);
-    });
-    if (nl) {
-      double gv[3];
-      cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+    for (int i = 0; i < 2; i++) {
+      u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
+      v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+      dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
+    }
+    const bool nl = (k + 1 <= N - 1);
+    // candidate index l: 0 = current point, l >= 1: alpha = a_pri * 2^-(l-1)
+    const int l_begin = phase == 0 ? 0 : 2 + cand, l_end = phase == 0 ? 1 : 2 + cand;
+    for (int l = l_begin; l <= l_end; l++) {
+      const double alpha = l == 0 ? 0.0 : ldexp(a_pri, -(l - 1));
+      double txk[8], txp[8], tc[8], tu[2], tv[2];
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
-        th += fabs(gv[q] + t), sl += log(t);
+      for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
+#pragma unroll
+      for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
+      double f1[8], f2[8];
+      rhs_val(K.p, K.T, eps, tc, tu, f1);
+      rhs_val(K.p, K.T, eps, txp, tu, f2);
+      double th = 0.0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
+        th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
       }
+      double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
+#pragma unroll
+      for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
+      double sl = 0.0;
+      const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
+        const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
+        const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+        th += fabs(sg * (xv - val) + t), sl += log(t);
+      });
+      if (nl) {
+        double gv[3];
+        cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
+          th += fabs(gv[q] + t), sl += log(t);
+        }
+      }
+      PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
     }
-    PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
-    alpha = (l == 0) ? a_pri : 0.5 * alpha;
   }
 }
 
@@ -1241,10 +1256,14 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W) {
 // Filter line search of Waechter & Biegler 2006 (no second-order correction, no restoration phase).
 #define STD(f) st[(size_t)(f) * W.Bp + b]
 #define STI(f) si[(size_t)(f) * W.Bp + b]
-__global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= W.nact[0]) return;
-  const int b = W.act[j];
+__global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
+  // 8 lanes per instance (lane = g + 8 i): lane i reduces the stage partials k = i, i+8, ...; the 8 lanes then hold
+  // the same numbers and take the same decisions, lane i == 0 writes.  (Keeps the latency of this small kernel at
+  // N/8 dependent loads instead of N.)
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int j = blockIdx.x * 8 + g;
+  if (j >= (phase == 0 ? W.nact[0] : W.ls_count[0])) return;
+  const int b = phase == 0 ? W.act[j] : W.ls_list[j];
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
@@ -1252,38 +1271,41 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
   const ltompc_options& o = K.o;
   const double mu = STD(ST_MU);
   double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
-  for (int k = 0; k < N; k++) {
+  for (int k = i; k < N; k += 8) {
     a_pri = fmin(a_pri, PL(W.SP, SP_apri, k, N)), a_dua = fmin(a_dua, PL(W.SP, SP_adua, k, N));
     gphid += PL(W.SP, SP_gphid, k, N);
   }
+  a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
   // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
   double c00;
   {
     double x0[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
+    for (int q = 0; q < 8; q++) x0[q] = W.x0[(size_t)q * W.Bp + b];
     c00 = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
   }
   auto measures = [&](int l, double& th, double& ph) {
-    double t = 0.0, c = c00, s = 0.0;
-    for (int k = 0; k < N; k++) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
-    th = t, ph = c - mu * s;
+    double t = 0.0, c = 0.0, s = 0.0;
+    for (int k = i; k < N; k += 8) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
+    t = grp_sum(t), c = grp_sum(c), s = grp_sum(s);
+    th = t, ph = (c00 + c) - mu * s;
   };
   double th0, ph0;
   measures(0, th0, ph0);
   double theta0 = STD(ST_THETA0);
   int nfilt = STI(SI_NFILT);
+  double theta_max = STD(ST_THMAX), theta_min = STD(ST_THMIN);
   if (theta0 < 0.0) {
-    theta0 = th0;
-    STD(ST_THETA0) = theta0, STD(ST_THMAX) = 1e4 * fmax(1.0, theta0), STD(ST_THMIN) = 1e-4 * fmax(1.0, theta0);
+    theta0 = th0, theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
+    if (i == 0) STD(ST_THETA0) = theta0, STD(ST_THMAX) = theta_max, STD(ST_THMIN) = theta_min;
     nfilt = 0;
   }
-  const double theta_max = STD(ST_THMAX), theta_min = STD(ST_THMIN);
   const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0;
   bool accepted = false;
   double alpha = a_pri;
   const int n_ls = o.n_linesearch;
-  for (int l = 0; l < n_ls; l++, alpha *= 0.5) {
+  const int n_try = (phase == 0) ? 1 : n_ls;  // phase 1 repeats the test of candidate 0 (same outcome) and goes on
+  for (int l = 0; l < n_try; l++, alpha *= 0.5) {
     double th, ph;
     measures(l + 1, th, ph);
     if (!isfinite(th) || !isfinite(ph) || th > theta_max) continue;
@@ -1300,20 +1322,33 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
     if (th0 <= theta_min && sw) ok = armijo;
     else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
     if (!ok) continue;
-    if (!(sw && armijo)) {
+    if (!(sw && armijo)) {  // augment the filter (written by lane i == 0, nobody reads it again in this launch)
       if (nfilt == FILTER_MAX) {
-        for (int f = 0; f + 1 < FILTER_MAX; f++) {
-          W.filt[(size_t)(2 * f) * W.Bp + b] = W.filt[(size_t)(2 * f + 2) * W.Bp + b];
-          W.filt[(size_t)(2 * f + 1) * W.Bp + b] = W.filt[(size_t)(2 * f + 3) * W.Bp + b];
-        }
+        if (i == 0)
+          for (int f = 0; f + 1 < FILTER_MAX; f++) {
+            W.filt[(size_t)(2 * f) * W.Bp + b] = W.filt[(size_t)(2 * f + 2) * W.Bp + b];
+            W.filt[(size_t)(2 * f + 1) * W.Bp + b] = W.filt[(size_t)(2 * f + 3) * W.Bp + b];
+          }
         nfilt--;
       }
-      W.filt[(size_t)(2 * nfilt) * W.Bp + b] = (1.0 - g_th) * th0;
-      W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * th0;
+      if (i == 0) {
+        W.filt[(size_t)(2 * nfilt) * W.Bp + b] = (1.0 - g_th) * th0;
+        W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * th0;
+      }
       nfilt++;
     }
     accepted = true;
     break;
+  }
+  if (i != 0) return;  // one writer per instance from here on
+  if (phase == 0) {
+    STI(SI_LSMORE) = (!accepted && n_ls > 1) ? 1 : 0;
+    if (!accepted && n_ls > 1) {  // nothing has been modified yet: phase 1 decides
+      W.ls_list[atomicAdd(W.ls_count, 1)] = b;
+      return;
+    }
+  } else {
+    STI(SI_LSMORE) = 0;
   }
   bool take = true, give_up = false;
   if (!accepted) {
@@ -1357,6 +1392,7 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W) {
 // ------------------------------------------------------------------------------------------ k_update
 __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
   int j = tid % W.n_pad, k = tid / W.n_pad;
   const int N = W.N;
   if (k >= N || j >= W.nact[0]) return;

@@ -45,6 +45,7 @@ struct ltompc_solver {
   int* h_active = nullptr;     // pinned
   int *d_act[2] = {nullptr, nullptr}, *d_nact[2] = {nullptr, nullptr};  // ping-pong lists of unfinished instances
   int last_compactions = 0;
+  std::vector<int> history;  // (iteration, n_active, n_launch) triples of the last make_step's polls
   bool cold_next = true;
   int poll_every = 4;
   bool profiling = false;
@@ -218,6 +219,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.st, (size_t)ST_NF * Bp), rc |= h->dalloc(&W.filt, (size_t)2 * FILTER_MAX * Bp);
   rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
+  rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
     ltompc_destroy(h);
@@ -300,6 +302,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
   hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
+  HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, sizeof(int), h->stream));
   h->cold_next = false;
   // all instances unfinished: identity list
   int cur = 0, n_launch = B;
@@ -315,6 +318,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   };
   set_launch(B);
   h->last_compactions = 0;
+  h->history.clear();
   int it = 0;
   for (;; it++) {
     const int np = W.n_pad;
@@ -326,13 +330,19 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
     if (L.run(2, k_expand, N * np, h->K, W)) return -1;
-    if (L.run(3, k_linesearch, N * np, h->K, W)) return -1;
-    if (L.run(4, k_pick, np, h->K, W)) return -1;
+    if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
+    if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
+    if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
+      const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
+      if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->K, W, 1, jw)) return -1;
+      if (L.run(4, k_pick, np * 8, h->K, W, 1)) return -1;
+    }
     if (L.run(5, k_update, N * np, h->K, W)) return -1;
     if ((it + 1) % h->poll_every == 0) {
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
+      h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
       if (h->compaction && n_active <= (3 * n_launch) / 4) {
         // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack the list
@@ -470,6 +480,14 @@ int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_k
   if (launches) *launches = h->last_launches;
   if (ip_iterations) *ip_iterations = h->last_iterations;
   return 0;
+}
+
+int ltompc_get_history(ltompc_handle h, int* triples, int capacity) {
+  if (!h) return fail("null handle");
+  int n = (int)h->history.size() / 3;
+  for (int i = 0; i < n && i < capacity; i++)
+    for (int j = 0; j < 3; j++) triples[3 * i + j] = h->history[3 * i + j];
+  return n;
 }
 
 // Test hook: model derivatives at n points (host arrays): x, lam: n x 8 -> f: n x 8, J, H: n x 64 (row-major 8x8),

@@ -114,6 +114,11 @@ class BatchedMPC:
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
 
+    def history(self):
+        buf = np.zeros((4096, 3), dtype=np.int32)
+        n = lib().ltompc_get_history(self._h, iptr(buf), 4096)
+        return buf[:max(0, min(n, 4096))]
+
     def test_model(self, x, lam, eps: float = 0.0):
         x = np.ascontiguousarray(np.asarray(x, float).reshape(-1, NX))
         lam = np.ascontiguousarray(np.asarray(lam, float).reshape(-1, NX))

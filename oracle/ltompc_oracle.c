@@ -1031,6 +1031,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         filt_th[nfilt] = (1 - g_th) * th0, filt_ph[nfilt] = ph0 - g_ph * th0, nfilt++;
       }
       accepted = 1;
+      if (getenv("ORACLE_LSHIST")) fprintf(stderr, "LS %d\n", l);
       break;
     }
     if (!accepted) {

@@ -8,4 +8,5 @@ m = ltompc.BatchedMPC(T, N, B, options=o); m.set_initial_guess(x0)
 u0 = m.make_step(x0)
 x0 = m.plant_step(x0, u0)
 u0 = m.make_step(x0)
+print("history", m.history().tolist())
 print("done", m.timing()["ip_iterations"], np.bincount(m.stats()["status"], minlength=5))
