@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--max-iter", type=int, default=150, help="interior-point iteration budget per solve")
-    ap.add_argument("--cpu-sample", type=int, default=192, help="instances solved by the CPU oracle for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances solved by the CPU oracle for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     args = ap.parse_args()

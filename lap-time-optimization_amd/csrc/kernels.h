@@ -177,6 +177,7 @@ struct Slot {
   double gs[3], gn[3], gm[3];        // gradients of gL, gR+, gR-
   double gv[3];                      // values of gL, gR+, gR- at x_{k+1}
   double rp_ineq, cmax, cmin, smult; // WITH_DUAL: max |h + t|, max / min t nu, sum |nu| over the slot's inequalities
+  double th_ineq, sumlog;            // WITH_DUAL: sum |h + t|, sum log t (filter measures of the current point)
   double cost;
   int m_nl;                          // storage index of gL
   bool nl;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   S.Du[0] = S.Du[1] = 0.0, S.gub0[0] = S.gub0[1] = 0.0, S.gub1[0] = S.gub1[1] = 0.0, S.dud[0] = S.dud[1] = 0.0;
   // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
   // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
-  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0;
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
   const int m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double hv = sg * (xv - val);
@@ -241,6 +242,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
     if (WITH_DUAL) {
       S.rp_ineq = fmax(S.rp_ineq, fabs(hv + t));
       S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+      S.th_ineq += fabs(hv + t), S.sumlog += log(t);
     }
   });
   S.m_nl = m_nl;
@@ -266,6 +268,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
       if (WITH_DUAL) {
         S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
         S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+        S.th_ineq += fabs(S.gv[q] + t), S.sumlog += log(t);
       }
     }
   } else {
@@ -419,6 +422,11 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
     }
     rp = fmax(rp, S.rp_ineq), sm += S.smult;
     const double cmax = S.cmax, cmin = S.cmin;
+    // filter measures of the current point (candidate 0 of the line search) come for free here
+    double th0 = S.th_ineq;
+#pragma unroll
+    for (int a = 0; a < 8; a++) th0 += fabs(S.G1[a]) + fabs(S.G2[a]);
+    PL(W.LS, 0, k, N) = th0, PL(W.LS, 1, k, N) = cost, PL(W.LS, 2, k, N) = S.sumlog;
     PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
     PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
   }
@@ -816,7 +824,7 @@ __device__ __forceinline__ void load_fwd(const Work& W, int b, int i, int k, Fwd
   f.b = PG(W.QP, QP_b + i, k, QP_NF);
 }
 
-__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index) {
+__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index, int max_sweeps) {
   __shared__ RicLds L;
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   const int jj = blockIdx.x * 8 + g;
@@ -901,7 +909,10 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
   int tries = 0;
   if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
   bool numerical = false;
-  {
+  // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
+  // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
+  // once only the stragglers are left
+  for (int sweep = 0;; sweep++) {
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
 #pragma unroll
@@ -1031,19 +1042,24 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index)
       }
       cur = nxt;
     }
-    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC), one attempt per launch
-    if (live && !ok) {
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
+    const bool failed = live && !ok;
+    if (failed) {
       if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
       else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
       if (++tries > 40 || delta_w > 1e20) numerical = true;
+      if (i == 0) STI(SI_NREG) += 1;
+    }
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    if (failed && !again) {  // continue in the next launch (or give up)
       if (i == 0) {
-        STI(SI_NREG) += 1;
         STI(SI_STEP) = 0;
         if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
         else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = delta_w;
       }
       live = false;
     }
+    if (!__any(again)) break;
   }
   if (live && i == 0) {
     STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
@@ -1180,7 +1196,7 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
 // Two phases (97% of all iterations accept the full step): phase 0 evaluates the current point and the first candidate
 // for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
 __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, int jw) {
-  // phase 0: thread = (k, j), evaluates the current point and the first candidate of instance act[j].
+  // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
   // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
   //          list of rejected instances; jw = launch width in instances, longer lists are covered grid-stride.
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1212,7 +1228,7 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, 
     }
     const bool nl = (k + 1 <= N - 1);
     // candidate index l: 0 = current point, l >= 1: alpha = a_pri * 2^-(l-1)
-    const int l_begin = phase == 0 ? 0 : 2 + cand, l_end = phase == 0 ? 1 : 2 + cand;
+    const int l_begin = phase == 0 ? 1 : 2 + cand, l_end = l_begin;  // l = 0 (current point) is written by k_eval
     for (int l = l_begin; l <= l_end; l++) {
       const double alpha = l == 0 ? 0.0 : ldexp(a_pri, -(l - 1));
       double txk[8], txp[8], tc[8], tu[2], tv[2];

@@ -326,7 +326,10 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->K, W, it)) return -1;
     } else {
-      if (L.run(1, k_riccati8, np * 8, h->K, W, it)) return -1;  // 8 lanes per instance
+      // measured: letting the stragglers retry inside a launch (max_sweeps 4 when n_launch <= 256) finishes them in
+      // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
+      const int max_sweeps = 1;
+      if (L.run(1, k_riccati8, np * 8, h->K, W, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
     if (L.run(2, k_expand, N * np, h->K, W)) return -1;
