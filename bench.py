@@ -157,6 +157,35 @@ def main():
         extras["batch1_iters_last"] = int(m1.iters[0])
         m1.close()
 
+    # ---- same workload with the warm start tuned for MPC (extension, not the reference's solver settings): previous
+    #      solution shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same
+    #      tolerance; reported as an extra, the headline `value` keeps do_mpc/IPOPT's defaults.
+    if rank == 0:
+        to = ltompc.default_options()
+        to.max_iter, to.warm_shift, to.mu_init_warm = args.max_iter, 1, 1e-3
+        mt = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=to, device=local_rank)
+        mt.set_stream(stream.cuda_stream)
+        xt = torch.from_numpy(x0_host).to(dev)
+        xtn, ut = torch.empty_like(xt), torch.zeros(B, 2, dtype=torch.float64, device=dev)
+        mt.set_initial_guess_dev(xt.data_ptr())
+        launched = []
+        for s in range(args.warmup + args.steps):
+            if s == args.warmup:
+                torch.cuda.synchronize(dev)
+                tt = time.perf_counter()
+            mt.make_step_dev(xt.data_ptr(), ut.data_ptr())
+            mt.plant_step_dev(xt.data_ptr(), ut.data_ptr(), xtn.data_ptr(), 400)
+            xt, xtn = xtn, xt
+            launched.append(mt.timing()["ip_iterations"])
+        torch.cuda.synchronize(dev)
+        tt = time.perf_counter() - tt
+        stt = mt.stats()
+        extras["tuned_warm_start"] = {"options": {"warm_shift": 1, "mu_init_warm": 1e-3}, "solves_per_s": B * args.steps / tt,
+                                      "ms_per_step": 1e3 * tt / args.steps, "solved_frac_last_tick": float((stt["status"] == 0).mean()),
+                                      "ip_iters_mean_last_tick": float(stt["iters"].mean()),
+                                      "ip_iterations_launched_per_tick": launched[args.warmup:]}
+        mt.close()
+
     # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on the host cores, bounded sample
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:

@@ -76,6 +76,10 @@ typedef struct ltompc_options {
    * smooth_scale * mu_barrier) in rad resp. metres; both 0 = the exact non-smooth functions. */
   double smooth_eps_min;  /* 1e-4 */
   double smooth_scale;    /* 1.0  */
+  /* Barrier parameter at the start of a WARM-started solve (every make_step after the first).  0 = use mu_init, which
+   * is what do_mpc/IPOPT do (IPOPT restarts at mu_init = 0.1 on every call); a smaller value (1e-3 .. 1e-2) keeps
+   * the iterates close to the previous solution and saves iterations without changing the KKT point found. */
+  double mu_init_warm;    /* 0 */
   int max_iter;           /* controller.py:18 says 1000 */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
@@ -83,7 +87,8 @@ typedef struct ltompc_options {
   int max_ls_fail;        /* stop (status STALLED) after this many failed line searches in one solve; 0 = off.
                              IPOPT would enter its restoration phase at the first one and, on a locally infeasible
                              problem, end with 'restoration failed'                                       (8) */
-  int reserved;
+  int warm_shift;         /* 0 (do_mpc: previous solution re-used as is) | 1: a warm start shifts the previous solution
+                             by one interval (x_k <- x_{k+1}, ..., last interval repeated) before solving      (0) */
 } ltompc_options;
 
 typedef struct ltompc_solver* ltompc_handle;

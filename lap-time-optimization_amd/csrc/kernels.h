@@ -355,7 +355,7 @@ __global__ void k_init(Consts K, Work W, int cold) {
 #pragma unroll
   for (int i = 0; i < 8; i++) xp[i] = cold ? x0[i] : PL(W.X, i, k + 1, N + 1), c[i] = cold ? x0[i] : PL(W.C, i, k, N);
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
-  const double mu = K.o.mu_init;
+  const double mu = (!cold && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
   auto put = [&](int mm, double hv) {
     double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
@@ -378,6 +378,40 @@ __global__ void k_init(Consts K, Work W, int cold) {
     st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
     for (int i = 0; i < SI_NF; i++) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ k_shift
+// Option warm_shift: previous solution moved one interval ahead (x_k <- x_{k+1}, c/u/multipliers likewise, the last
+// interval repeated).  Two passes through the step buffers so that no thread reads what another one overwrites.
+__global__ void k_shift(Work W, int pass) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k > N || b >= W.B) return;
+  if (pass == 0) {
+    const int kx = k + 1 <= N ? k + 1 : N, ks = k + 1 <= N - 1 ? k + 1 : N - 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.dX, i, k, N + 1) = PL(W.X, i, kx, N + 1);
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        PL(W.dC, i, k, N) = PL(W.C, i, ks, N);
+        PL(W.nL1, i, k, N) = PL(W.L1, i, ks, N), PL(W.nL2, i, k, N) = PL(W.L2, i, ks, N);
+      }
+      PL(W.dU, 0, k, N) = PL(W.U, 0, ks, N), PL(W.dU, 1, k, N) = PL(W.U, 1, ks, N);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.X, i, k, N + 1) = PL(W.dX, i, k, N + 1);
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        PL(W.C, i, k, N) = PL(W.dC, i, k, N);
+        PL(W.L1, i, k, N) = PL(W.nL1, i, k, N), PL(W.L2, i, k, N) = PL(W.nL2, i, k, N);
+      }
+      PL(W.U, 0, k, N) = PL(W.dU, 0, k, N), PL(W.U, 1, k, N) = PL(W.dU, 1, k, N);
+    }
   }
 }
 

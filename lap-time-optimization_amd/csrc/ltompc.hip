@@ -300,6 +300,10 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   Launcher L{h};
   hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
   if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
+  if (!h->cold_next && h->K.o.warm_shift) {
+    hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 0);
+    hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 1);
+  }
   hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
   HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, sizeof(int), h->stream));

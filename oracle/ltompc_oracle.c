@@ -618,9 +618,20 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     memcpy(it.u, U, sizeof(double) * (size_t)N * NU);
     memcpy(it.l1, L1, sizeof(double) * (size_t)N * NX);
     memcpy(it.l2, L2, sizeof(double) * (size_t)N * NX);
+    if (o->warm_shift) { /* option: shift the previous solution by one interval (last interval repeated) */
+      for (int k = 0; k + 1 < N; k++) {
+        memcpy(it.x + k * NX, X + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it.c + k * NX, C + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it.u + k * NU, U + (k + 1) * NU, sizeof(double) * NU);
+        memcpy(it.l1 + k * NX, L1 + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it.l2 + k * NX, L2 + (k + 1) * NX, sizeof(double) * NX);
+      }
+      memcpy(it.x + (N - 1) * NX, X + N * NX, sizeof(double) * NX);
+    }
     memcpy(it.x, x0, sizeof(double) * NX); /* node 0 is the measured state */
   }
-  double mu = o->mu_init;
+  double mu = (warm && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
+  SET_SMOOTHING(mu);
   for (int k = 0; k < N; k++) {
     double h[MAXI];
     int act[MAXI];

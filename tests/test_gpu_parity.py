@@ -185,3 +185,49 @@ def test_gpu_error_behaviour(pkg, tables, gpu_lib):
     with pytest.raises(pkg.LtompcError):
         pkg.BatchedMPC(tables, 1, 4)                    # horizon out of range
     mpc.close()
+
+
+def test_warm_start_options_match_oracle(pkg, tables, orc, gpu_lib):
+    """Extension options (shifted warm start, reduced initial barrier for warm solves) against the oracle with the
+    same options: 3 warm ticks, B=32, N=20."""
+    B, N = 32, 20
+    o = pkg.default_options(); o.warm_shift, o.mu_init_warm = 1, 1e-3
+    oo = orc.default_options(); oo.warm_shift, oo.mu_init_warm = 1, 1e-3
+    oracle = orc.Oracle(tables.packed(), options=oo)
+    x0 = pkg.sample_x0(tables, B, seed=21)
+    mpc = pkg.BatchedMPC(tables, N, B, options=o)
+    mpc.set_initial_guess(x0)
+    ref, uprev = None, np.zeros((B, 2))
+    base_iters = None
+    for tick in range(4):
+        u0 = mpc.make_step(x0)
+        ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8)
+        both = (mpc.status == 0) & (ref["status"] == 0)
+        assert both.mean() > 0.85, (tick, both.mean())
+        assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, tick
+        if tick == 0:
+            base_iters = mpc.iters[both].mean()
+        x0, uprev = oracle.plant_step(x0, ref["u0"]), ref["u0"]
+    assert mpc.iters[both].mean() < 0.8 * base_iters  # the tuned warm start needs clearly fewer iterations than a cold start
+    mpc.close()
+
+
+def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_lib, monkeypatch):
+    """Packing of unfinished instances and the wave-cooperative Riccati kernel are pure scheduling: results are
+    bit-identical with compaction switched off, and equal to 1e-9 with the one-thread-per-instance Riccati kernel."""
+    B, N = 300, 20
+    x0 = pkg.sample_x0(tables, B, seed=9)
+    def run():
+        m = pkg.BatchedMPC(tables, N, B)
+        m.set_initial_guess(x0)
+        u = m.make_step(x0); s = m.stats(); m.close()
+        return u, s
+    u_ref, s_ref = run()
+    monkeypatch.setenv("LTOMPC_COMPACT", "0")
+    u_nc, s_nc = run()
+    assert np.array_equal(u_nc, u_ref) and np.array_equal(s_nc["iters"], s_ref["iters"])
+    monkeypatch.delenv("LTOMPC_COMPACT")
+    monkeypatch.setenv("LTOMPC_RICCATI", "serial")
+    u_se, s_se = run()
+    ok = (s_se["status"] == 0) & (s_ref["status"] == 0)
+    assert ok.mean() > 0.9 and np.abs(u_se - u_ref)[ok].max() < 1e-6
