@@ -30,6 +30,7 @@ BYTES_PER_STAGE_ITER = 8 * (2 * WORDS_QP + WORDS_RIC_OUT + WORDS_EVAL_IN)  # 310
 BYTES_BY_KERNEL = {  # share of the 3104 B each kernel class moves (algorithmic, not measured traffic)
     "eval": 8 * (WORDS_QP + WORDS_EVAL_IN), "riccati": 8 * (WORDS_QP + WORDS_RIC_OUT),
     "expand": 8 * (WORDS_EVAL_IN + WORDS_RIC_OUT), "linesearch": 8 * WORDS_EVAL_IN, "pick": 0, "update": 8 * 2 * WORDS_EVAL_IN,
+    "tail": 0,  # straggler kernel: latency-bound by construction, no roofline claim
 }
 
 
@@ -126,7 +127,7 @@ def main():
     roofline = None
     if not args.no_profile and rank == 0:
         ms, ln = tm["ms"], tm["launches_by_kernel"]
-        dom = max(ms, key=lambda k: ms[k])
+        dom = max((k for k in ms if BYTES_BY_KERNEL[k] > 0), key=lambda k: ms[k])  # dominant wide (HBM-streaming) kernel
         avg_ms = ms[dom] / max(1, ln[dom])
         # instances still iterating, averaged over launches (finished instances idle inside a launch)
         active_per_launch = float(st["iters"].sum()) * args.steps / max(1, sum(per_tick))  # last tick's distribution

@@ -163,10 +163,11 @@ int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:
- * index 0 eval, 1 riccati, 2 expand, 3 linesearch, 4 pick, 5 update.  launches / ip_iterations refer to the
- * last make_step.  Any output may be NULL. */
+ * index 0 eval, 1 riccati, 2 expand, 3 linesearch, 4 pick, 5 update, 6 tail (the one-wavefront-per-instance kernel that
+ * finishes the stragglers).  launches / ip_iterations (wide iterations launched) refer to the last make_step.
+ * Arrays have 7 entries.  Any output may be NULL. */
 int ltompc_set_profiling(ltompc_handle h, int on);
-int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_kernel6, int* launches,
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_kernel7, int* launches,
                       int* ip_iterations);
 
 /* Poll history of the last make_step: up to `capacity` triples (iteration, unfinished instances, launch width);
@@ -175,6 +176,9 @@ int ltompc_get_history(ltompc_handle h, int* triples, int capacity);
 
 /* make_step polls the device's count of unfinished instances every n interior-point iterations (default 4). */
 int ltompc_set_poll_every(ltompc_handle h, int n);
+
+/* Debug hook: raw copy of a device work array in its device layout (see csrc/kernels.h); returns its size in bytes. */
+long long ltompc_debug_fetch(ltompc_handle h, int which, void* out, long long nbytes);
 
 /* Test hook (not part of the reference surface): model derivatives at n points, computed by the same device
  * functions the solver kernels use.  x, lam: n x 8 -> f: n x 8; J (df/dx), H (sum_i lam_i d2f_i): n x 8 x 8;

@@ -7,7 +7,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libltompc.so")
-SOURCES = ["ltompc.hip", "kernels.h", "model.h", os.path.join("..", "..", "include", "ltompc.h")]
+SOURCES = ["ltompc.hip", "kernels.h", "model.h", os.path.join("..", "..", "include", "ltompc.h"), os.path.join("..", "_build.py")]
 
 
 def needs_build() -> bool:
@@ -22,7 +22,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=on",
            os.path.join(CSRC, "ltompc.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd))

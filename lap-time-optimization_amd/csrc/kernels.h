@@ -78,6 +78,7 @@ struct Work {
   const int* act;
   const int* nact;
   int n_launch, n_pad;  // n_pad = n_launch rounded up to a multiple of 64
+  double* DBG;  // [8][N][Bp] scratch planes for debugging
   int *ls_list, *ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
   int debug_extra_sweeps;
 };
@@ -357,17 +358,19 @@ __global__ void k_init(Consts K, Work W, int cold) {
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
   const double mu = (!cold && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
-  auto put = [&](int mm, double hv) {
-    double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
-    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
-  };
+  // (flat visitor, no nested by-reference lambdas: see d_expand)
   const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
-    put(mm, sg * (xv - val));
+    const double hv = sg * (xv - val);
+    const double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
+    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
   });
   double gv[3] = {-1.0, -1.0, -1.0};
   if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
-  for (int q = 0; q < 3; q++) put(m + q, gv[q]);
+  for (int q = 0; q < 3; q++) {
+    const double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push;
+    PL(W.T, m + q, k, N) = t, PL(W.NU, m + q, k, N) = mu / t;
+  }
   if (k == 0) {
     double* st = W.st;
     st[(size_t)ST_MU * W.Bp + b] = mu, st[(size_t)ST_EPS * W.Bp + b] = eps, st[(size_t)ST_EPS_NEXT * W.Bp + b] = eps;
@@ -416,12 +419,8 @@ __global__ void k_shift(Work W, int pass) {
 }
 
 // ------------------------------------------------------------------------------------------ k_eval
-__global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = tid % W.n_pad, k = tid / W.n_pad;
+__device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
-  if (k >= N || j >= W.nact[0]) return;
-  const int b = W.act[j];
   if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
   if (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b]) return;  // blocks of the last launch are still valid
   const double hdt = K.o.t_step;
@@ -507,6 +506,13 @@ __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
   for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k, QP_NF) = S.Hxp[i];
 #pragma unroll
   for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k, QP_NF) = S.gxp1[i];
+}
+
+__global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
+  if (k >= W.N || j >= W.nact[0]) return;
+  d_eval(K, W, k, W.act[j]);
 }
 
 // ------------------------------------------------------------------------------------------ k_riccati
@@ -858,12 +864,10 @@ __device__ __forceinline__ void load_fwd(const Work& W, int b, int i, int k, Fwd
   f.b = PG(W.QP, QP_b + i, k, QP_NF);
 }
 
-__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index, int max_sweeps) {
-  __shared__ RicLds L;
-  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int jj = blockIdx.x * 8 + g;
-  const bool valid = jj < W.nact[0];
-  const int b = W.act[valid ? jj : 0];  // padding lanes shadow a real instance read-only
+// All 64 lanes of a wavefront call this together; lane (g, i) works on row i of instance b (padding lanes: valid =
+// false, they shadow a real instance read-only).  active_slot >= 0: count the unfinished instances there.
+__device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLds& L, const int g, const int i, const int b,
+                                           const bool valid, const int active_slot, const int max_sweeps) {
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
@@ -916,7 +920,7 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index,
     }
     if (term >= 0) live = false;
   }
-  if (live && i == 0) atomicAdd(&W.active[it_index], 1);
+  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
   if (!__any(live)) return;
   // ---- monotone barrier update
   bool mu_changed = false;
@@ -1137,13 +1141,17 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index,
 #undef STI
 }
 
+__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index, int max_sweeps) {
+  __shared__ RicLds L;
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int jj = blockIdx.x * 8 + g;
+  const bool valid = jj < W.nact[0];
+  d_riccati8(K, W, L, g, i, W.act[valid ? jj : 0], valid, it_index, max_sweeps);
+}
+
 // ------------------------------------------------------------------------------------------ k_expand
-__global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = tid % W.n_pad, k = tid / W.n_pad;
+__device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
-  if (k >= N || j >= W.nact[0]) return;
-  const int b = W.act[j];
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
   const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
@@ -1201,27 +1209,43 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
   }
 #pragma unroll
   for (int a = 0; a < 8; a++) gphid += S.gcost[a] * dxp[a];
-  auto slack_step = [&](int m, double hv, double gd) {
-    double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
-    double dtt = -(hv + t) - gd;
-    double dn = (mu - nu * dtt) / t - nu;
+  // (one flat visitor: an earlier version with a second, nested by-reference lambda produced run-to-run varying
+  //  values of gphid for the last interval on ROCm 7.2 / gfx950, a code-generation problem that instrumenting stores
+  //  made disappear; tests/test_gpu_parity.py::test_full_size_batch_properties guards against its return)
+  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
+    const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+    const double dtt = -(sg * (xv - val) + t) - sg * dv;
+    const double dn = (mu - nu * dtt) / t - nu;
     PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
     if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
     if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
     gphid -= mu * dtt / t;
-  };
-  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
-    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
-    const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
-    slack_step(m, sg * (xv - val), sg * dv);
   });
 #pragma unroll
   for (int q = 0; q < 3; q++) {
     const int m = S.m_nl + q;
-    if (S.nl) slack_step(m, S.gv[q], S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
-    else PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+    if (S.nl) {
+      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+      const double dtt = -(S.gv[q] + t) - (S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
+      const double dn = (mu - nu * dtt) / t - nu;
+      PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+      if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+      if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+      gphid -= mu * dtt / t;
+    } else {
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+    }
   }
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
+}
+
+__global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = tid % W.n_pad, k = tid / W.n_pad;
+  if (k >= W.N || j >= W.nact[0]) return;
+  d_expand(K, W, k, W.act[j]);
 }
 
 // ------------------------------------------------------------------------------------------ k_linesearch
@@ -1229,6 +1253,70 @@ __global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
 // LS plane layout: [3 * (n_ls + 1)][N][Bp] : theta, cost, sum log t per candidate.
 // Two phases (97% of all iterations accept the full step): phase 0 evaluates the current point and the first candidate
 // for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
+// Filter measures (theta, cost, sum log t) of the step candidates l_begin..l_end of interval k of instance b;
+// candidate l >= 1 has alpha = a_pri * 2^-(l-1) (l = 0, the current point, is written by k_eval).
+__device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, const int k, const int b, const int l_begin,
+                                             const int l_end) {
+  const int N = W.N;
+  const double hdt = K.o.t_step;
+  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  double a_pri = 1.0;
+  for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
+  double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+    dxk[i] = PL(W.dX, i, k, N + 1);
+    xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+    c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
+    v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+    dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
+  }
+  const bool nl = (k + 1 <= N - 1);
+  // candidate index l: 0 = current point, l >= 1: alpha = a_pri * 2^-(l-1)
+  for (int l = l_begin; l <= l_end; l++) {
+    const double alpha = l == 0 ? 0.0 : ldexp(a_pri, -(l - 1));
+    double txk[8], txp[8], tc[8], tu[2], tv[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
+    double f1[8], f2[8];
+    rhs_val(K.p, K.T, eps, tc, tu, f1);
+    rhs_val(K.p, K.T, eps, txp, tu, f2);
+    double th = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
+      th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
+    }
+    double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
+#pragma unroll
+    for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
+    double sl = 0.0;
+    const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
+      const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
+      const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+      th += fabs(sg * (xv - val) + t), sl += log(t);
+    });
+    if (nl) {
+      double gv[3];
+      cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
+        th += fabs(gv[q] + t), sl += log(t);
+      }
+    }
+    PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
+  }
+}
+
 __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, int jw) {
   // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
   // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
@@ -1236,84 +1324,21 @@ __global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, 
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = W.N;
   const int j0 = tid % jw, rest = tid / jw, k = rest % N, cand = rest / N;
-  const int n_ls = K.o.n_linesearch;
-  if (phase == 0 ? (rest >= N) : (cand >= n_ls - 1)) return;
+  if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
   const int count = phase == 0 ? W.nact[0] : W.ls_count[0];
-  const double hdt = K.o.t_step;
-  for (int j = j0; j < count; j += jw) {
-    const int b = phase == 0 ? W.act[j] : W.ls_list[j];
-    if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) continue;  // no step this launch
-    const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
-    double a_pri = 1.0;
-    for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
-    double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
-      dxk[i] = PL(W.dX, i, k, N + 1);
-      xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
-      c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
-      v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
-      dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
-    }
-    const bool nl = (k + 1 <= N - 1);
-    // candidate index l: 0 = current point, l >= 1: alpha = a_pri * 2^-(l-1)
-    const int l_begin = phase == 0 ? 1 : 2 + cand, l_end = l_begin;  // l = 0 (current point) is written by k_eval
-    for (int l = l_begin; l <= l_end; l++) {
-      const double alpha = l == 0 ? 0.0 : ldexp(a_pri, -(l - 1));
-      double txk[8], txp[8], tc[8], tu[2], tv[2];
-#pragma unroll
-      for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
-#pragma unroll
-      for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
-      double f1[8], f2[8];
-      rhs_val(K.p, K.T, eps, tc, tu, f1);
-      rhs_val(K.p, K.T, eps, txp, tu, f2);
-      double th = 0.0;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
-        th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
-      }
-      double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
-#pragma unroll
-      for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
-      double sl = 0.0;
-      const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
-        const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
-        const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
-        th += fabs(sg * (xv - val) + t), sl += log(t);
-      });
-      if (nl) {
-        double gv[3];
-        cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-          double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
-          th += fabs(gv[q] + t), sl += log(t);
-        }
-      }
-      PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
-    }
-  }
+  const int l = phase == 0 ? 1 : 2 + cand;
+  for (int j = j0; j < count; j += jw) d_linesearch(K, W, k, phase == 0 ? W.act[j] : W.ls_list[j], l, l);
 }
 
 // ------------------------------------------------------------------------------------------ k_pick
 // Filter line search of Waechter & Biegler 2006 (no second-order correction, no restoration phase).
 #define STD(f) st[(size_t)(f) * W.Bp + b]
 #define STI(f) si[(size_t)(f) * W.Bp + b]
-__global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
-  // 8 lanes per instance (lane = g + 8 i): lane i reduces the stage partials k = i, i+8, ...; the 8 lanes then hold
-  // the same numbers and take the same decisions, lane i == 0 writes.  (Keeps the latency of this small kernel at
-  // N/8 dependent loads instead of N.)
-  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int j = blockIdx.x * 8 + g;
-  if (j >= (phase == 0 ? W.nact[0] : W.ls_count[0])) return;
-  const int b = phase == 0 ? W.act[j] : W.ls_list[j];
+// 8 lanes per instance (lane = g + 8 i, all 8 lanes of a group call this together): lane i reduces the stage partials
+// k = i, i+8, ...; the 8 lanes then hold the same numbers and take the same decisions, lane i == 0 writes.  (Keeps the
+// latency of this small step at N/8 dependent loads instead of N.)
+__device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int b, const int i, const int phase,
+                                       const bool append_list) {
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
@@ -1394,7 +1419,7 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
   if (phase == 0) {
     STI(SI_LSMORE) = (!accepted && n_ls > 1) ? 1 : 0;
     if (!accepted && n_ls > 1) {  // nothing has been modified yet: phase 1 decides
-      W.ls_list[atomicAdd(W.ls_count, 1)] = b;
+      if (append_list) W.ls_list[atomicAdd(W.ls_count, 1)] = b;
       return;
     }
   } else {
@@ -1439,14 +1464,16 @@ __global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
   STI(SI_SKIP_EVAL) = (!take && !eps_switched) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
 }
 
+__global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int j = blockIdx.x * 8 + g;
+  if (j >= (phase == 0 ? W.nact[0] : W.ls_count[0])) return;
+  d_pick(K, W, phase == 0 ? W.act[j] : W.ls_list[j], i, phase, true);
+}
+
 // ------------------------------------------------------------------------------------------ k_update
-__global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
-  int j = tid % W.n_pad, k = tid / W.n_pad;
+__device__ __forceinline__ void d_update(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
-  if (k >= N || j >= W.nact[0]) return;
-  const int b = W.act[j];
   if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
   const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
   const double mu = W.st[(size_t)ST_MU * W.Bp + b];
@@ -1466,6 +1493,62 @@ __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
     double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
     PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
   }
+}
+
+__global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
+  int j = tid % W.n_pad, k = tid / W.n_pad;
+  if (k >= W.N || j >= W.nact[0]) return;
+  d_update(K, W, k, W.act[j]);
+}
+
+// ------------------------------------------------------------------------------------------ k_tail
+// The stragglers: one wavefront per unfinished instance runs the WHOLE remaining interior-point loop in one launch
+// (lane = interval for the interval-parallel phases, lanes g == 0 for the 8-lane Riccati / pick phases).  The wide
+// launches above are efficient while thousands of instances iterate in lock-step; the last <1% of the instances need
+// 40..150 iterations, and at that width every kernel of the sequence is pure launch + single-wave latency (~0.8 ms per
+// iteration, two thirds of a tick).  Here each straggler proceeds at its own pace, with no launch in between and
+// with the regularisation retries inside the iteration (exactly the oracle's iteration semantics).
+__global__ void __launch_bounds__(64) k_tail(Consts K, Work W, int max_passes) {
+  __shared__ RicLds L;
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  if ((int)blockIdx.x >= W.nact[0]) return;
+  const int b = W.act[blockIdx.x];
+  const int N = W.N;
+  const int* si = W.si;
+  const int dbg = W.debug_extra_sweeps & 255;  // bisecting aid: bit mask of the phases to run (0 = all), passes in bits 8..
+#define PH(bit) (dbg == 0 || (dbg & (bit)))
+  if (W.debug_extra_sweeps >> 8) max_passes = W.debug_extra_sweeps >> 8;
+  for (int pass = 0; pass < max_passes; pass++) {
+    if (si[(size_t)SI_DONE * W.Bp + b]) break;  // block-uniform: one instance per block
+    if (PH(1))
+      for (int k = lane; k < N; k += 64) d_eval(K, W, k, b);
+    __syncthreads();
+    if (PH(2)) d_riccati8(K, W, L, g, i, b, g == 0, -1, 8);
+    __syncthreads();
+    if (si[(size_t)SI_DONE * W.Bp + b]) break;
+    if (si[(size_t)SI_STEP * W.Bp + b]) {
+      if (PH(4))
+        for (int k = lane; k < N; k += 64) d_expand(K, W, k, b);
+      __syncthreads();
+      if (PH(8))
+        for (int k = lane; k < N; k += 64) d_linesearch(K, W, k, b, 1, 1);
+      __syncthreads();
+      if (PH(16) && g == 0) d_pick(K, W, b, i, 0, false);
+      __syncthreads();
+      if (PH(32) && si[(size_t)SI_LSMORE * W.Bp + b]) {
+        for (int k = lane; k < N; k += 64) d_linesearch(K, W, k, b, 2, K.o.n_linesearch);
+        __syncthreads();
+        if (g == 0) d_pick(K, W, b, i, 1, false);
+        __syncthreads();
+      }
+      if (PH(64))
+        for (int k = lane; k < N; k += 64) d_update(K, W, k, b);
+      __syncthreads();
+    }
+  }
+#undef PH
 }
 
 // ------------------------------------------------------------------------------------------ compaction

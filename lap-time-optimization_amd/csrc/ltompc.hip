@@ -28,7 +28,7 @@ int fail(const std::string& msg) {
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
   } while (0)
 
-constexpr int NKERN = 6;  // eval, riccati, expand, linesearch, pick, update
+constexpr int NKERN = 7;  // eval, riccati, expand, linesearch, pick, update, tail
 
 }  // namespace
 
@@ -53,8 +53,10 @@ struct ltompc_solver {
   bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
   std::vector<hipEvent_t> ev;  // pairs
   std::vector<int> ev_kind;
-  double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0};
-  int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0};
+  double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
+  int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
+  int tail_width = 1024;  // LTOMPC_TAIL: switch to one-wavefront-per-instance mode at this many unfinished instances (0 = never)
+  int last_tail_instances = 0;
   int last_launches = 0, last_iterations = 0;
 
   template <typename T>
@@ -199,6 +201,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->serial_riccati = e && std::string(e) == "serial";
     const char* c = getenv("LTOMPC_COMPACT");
     h->compaction = !(c && std::string(c) == "0");
+    const char* t = getenv("LTOMPC_TAIL");
+    if (t) h->tail_width = atoi(t);
   }
   const size_t N = h->N, Bp = h->Bp;
   const int ni = h->K.bd.ni;
@@ -220,6 +224,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
+  if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
     ltompc_destroy(h);
@@ -322,6 +327,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   };
   set_launch(B);
   h->last_compactions = 0;
+  h->last_tail_instances = 0;
   h->history.clear();
   int it = 0;
   for (;; it++) {
@@ -351,6 +357,30 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
       h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
+      if (h->compaction && !h->serial_riccati && n_active <= h->tail_width) {
+        // few instances left: re-pack and let each of them run its remaining iterations in one launch
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
+                           h->W.si + (size_t)SI_DONE * Bp, h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+        cur ^= 1;
+        set_launch(n_active);
+        h->last_compactions++;
+        h->last_tail_instances = n_active;
+        dim3 grid(n_active), block(64);
+        const int max_passes = 4 * h->max_iter + 64;  // passes that repeat a sweep or a line search do not count as iterations
+        if (h->profiling) {
+          hipEvent_t a, b;
+          if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail("hipEventCreate failed");
+          hipEventRecord(a, h->stream);
+          hipLaunchKernelGGL(k_tail, grid, block, 0, h->stream, h->K, W, max_passes);
+          hipEventRecord(b, h->stream);
+          h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(6);
+        } else {
+          hipLaunchKernelGGL(k_tail, grid, block, 0, h->stream, h->K, W, max_passes);
+        }
+        L.launches++;
+        it++;
+        break;
+      }
       if (h->compaction && n_active <= (3 * n_launch) / 4) {
         // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack the list
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
@@ -478,11 +508,11 @@ int ltompc_slip_forces(ltompc_handle h, const double* x, int batch, double* alph
   return 0;
 }
 
-int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel6, int* launches_by_kernel6, int* launches, int* ip_iterations) {
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_kernel7, int* launches, int* ip_iterations) {
   if (!h) return fail("null handle");
   for (int i = 0; i < NKERN; i++) {
-    if (ms_by_kernel6) ms_by_kernel6[i] = h->ms_by_kernel[i];
-    if (launches_by_kernel6) launches_by_kernel6[i] = h->launches_by_kernel[i];
+    if (ms_by_kernel7) ms_by_kernel7[i] = h->ms_by_kernel[i];
+    if (launches_by_kernel7) launches_by_kernel7[i] = h->launches_by_kernel[i];
   }
   if (launches) *launches = h->last_launches;
   if (ip_iterations) *ip_iterations = h->last_iterations;
@@ -495,6 +525,27 @@ int ltompc_get_history(ltompc_handle h, int* triples, int capacity) {
   for (int i = 0; i < n && i < capacity; i++)
     for (int j = 0; j < 3; j++) triples[3 * i + j] = h->history[3 * i + j];
   return n;
+}
+
+// Debug hook: raw copy of a device work array (layout as on the device).  which: 0 QP, 1 RC, 2 RS, 3 SP, 4 LS, 5 dX, 6 dU,
+// 7 dC, 8 dT, 9 dNU, 10 nL1, 11 nL2, 12 st, 13 si (ints).  Returns the number of bytes of the array (copies min(nbytes, size)).
+long long ltompc_debug_fetch(ltompc_handle h, int which, void* out, long long nbytes) {
+  if (!h) return fail("null handle");
+  const size_t N = h->N, Bp = h->Bp, ni = h->K.bd.ni;
+  const Work& W = h->W;
+  const void* src[15] = {W.QP, W.RC, W.RS, W.SP, W.LS, W.dX, W.dU, W.dC, W.dT, W.dNU, W.nL1, W.nL2, W.st, W.si, W.DBG};
+  const size_t sz[15] = {QP_NF * N * Bp * 8, RC_NF * (N + 1) * Bp * 8, RS_NF * N * Bp * 8, SP_NF * N * Bp * 8,
+                         3 * ((size_t)h->K.o.n_linesearch + 1) * N * Bp * 8, 8 * (N + 1) * Bp * 8, 2 * N * Bp * 8, 8 * N * Bp * 8,
+                         ni * N * Bp * 8, ni * N * Bp * 8, 8 * N * Bp * 8, 8 * N * Bp * 8, (size_t)ST_NF * Bp * 8, (size_t)SI_NF * Bp * 4,
+                         W.DBG ? 8 * N * Bp * 8 : 0};
+  if (which < 0 || which > 14) return fail("ltompc_debug_fetch: bad array id");
+  if (out && nbytes > 0) {
+    size_t n = std::min((size_t)nbytes, sz[which]);
+    if (hipSetDevice(h->device) != hipSuccess || hipMemcpyAsync(out, src[which], n, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess)
+      return fail("ltompc_debug_fetch: copy failed");
+  }
+  return (long long)sz[which];
 }
 
 // Test hook: model derivatives at n points (host arrays): x, lam: n x 8 -> f: n x 8, J, H: n x 64 (row-major 8x8),

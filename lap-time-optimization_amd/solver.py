@@ -107,10 +107,10 @@ class BatchedMPC:
         check(lib().ltompc_set_poll_every(self._h, int(n)))
 
     def timing(self):
-        ms, ln = np.zeros(6), np.zeros(6, dtype=np.int32)
+        ms, ln = np.zeros(7), np.zeros(7, dtype=np.int32)
         launches, its = C.c_int(), C.c_int()
         check(lib().ltompc_get_timing(self._h, dptr(ms), iptr(ln), C.byref(launches), C.byref(its)))
-        names = ("eval", "riccati", "expand", "linesearch", "pick", "update")
+        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "tail")
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
 
@@ -118,6 +118,13 @@ class BatchedMPC:
         buf = np.zeros((4096, 3), dtype=np.int32)
         n = lib().ltompc_get_history(self._h, iptr(buf), 4096)
         return buf[:max(0, min(n, 4096))]
+
+    def debug_fetch(self, which: int):
+        L = lib(); L.ltompc_debug_fetch.restype = C.c_longlong
+        n = L.ltompc_debug_fetch(self._h, int(which), None, C.c_longlong(0))
+        buf = np.empty(n // (4 if which == 13 else 8), dtype=np.int32 if which == 13 else np.float64)
+        L.ltompc_debug_fetch(self._h, int(which), buf.ctypes.data_as(C.c_void_p), C.c_longlong(n))
+        return buf
 
     def test_model(self, x, lam, eps: float = 0.0):
         x = np.ascontiguousarray(np.asarray(x, float).reshape(-1, NX))
