@@ -89,6 +89,10 @@ typedef struct ltompc_options {
                              problem, end with 'restoration failed'                                       (8) */
   int warm_shift;         /* 0 (do_mpc: previous solution re-used as is) | 1: a warm start shifts the previous solution
                              by one interval (x_k <- x_{k+1}, ..., last interval repeated) before solving      (0) */
+  int warm_reset_on_fail; /* 1: a warm start after a solve that did NOT converge keeps that solve's primal point but
+                             restarts the equality multipliers at 0 and the barrier at mu_init (IPOPT's default
+                             warm_start_init_point=no never re-uses multipliers; ours are re-used after a converged
+                             solve only, the ones of a failed solve are what diverged) | 0: always re-use       (1) */
 } ltompc_options;
 
 typedef struct ltompc_solver* ltompc_handle;

@@ -58,7 +58,7 @@ enum : int {
 // SI_RETRY: the last Riccati sweep failed the inertia test; the next launch repeats it with ST_DW_TRY (no new
 // evaluation).  SI_SKIP_EVAL: the iterate did not move (failed line search), k_eval's output is still valid.
 enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
-             SI_SKIP_EVAL, SI_LSMORE, SI_NF };
+             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
 
 struct Work {
   int N, B, Bp;
@@ -352,11 +352,19 @@ __global__ void k_init(Consts K, Work W, int cold) {
     }
     PL(W.U, 0, k, N) = 0.0, PL(W.U, 1, k, N) = 0.0;
   }
+  // Option warm_reset_on_fail: the multipliers of a solve that did not converge are not worth starting from (they are
+  // what diverged): keep its primal point, restart the equality multipliers at 0 and the barrier at the cold mu_init.
+  const int prev = W.si[(size_t)SI_PREV * W.Bp + b];
+  const bool after_failure = !cold && K.o.warm_reset_on_fail && prev != LTOMPC_STATUS_SOLVED && prev != LTOMPC_STATUS_ACCEPTABLE;
+  if (after_failure) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
+  }
   double xp[8], c[8], u[2];
 #pragma unroll
   for (int i = 0; i < 8; i++) xp[i] = cold ? x0[i] : PL(W.X, i, k + 1, N + 1), c[i] = cold ? x0[i] : PL(W.C, i, k, N);
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
-  const double mu = (!cold && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
+  const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
   // (flat visitor, no nested by-reference lambdas: see d_expand)
   const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
@@ -379,7 +387,8 @@ __global__ void k_init(Consts K, Work W, int cold) {
     st[(size_t)ST_E0 * W.Bp + b] = 1e300, st[(size_t)ST_OBJ * W.Bp + b] = 0.0, st[(size_t)ST_TAU * W.Bp + b] = 0.99;
     st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
     st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
-    for (int i = 0; i < SI_NF; i++) W.si[(size_t)i * W.Bp + b] = 0;
+    for (int i = 0; i < SI_NF; i++)
+      if (i != SI_PREV) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
   }
 }
@@ -1141,6 +1150,300 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
 #undef STI
 }
 
+// ---- single-instance form of the sweep (k_tail): all 64 lanes work on ONE instance, lane (g, i) computes column g of
+// row i of the 8x8 products instead of all 8 columns, with the SAME per-element expressions as d_riccati8, so that the
+// bits do not depend on which of the two a solve goes through.  LDS slot [field][0] is shared by the 8 column lanes.
+struct Stage1Regs {
+  double a, bb, b, q_elem, S[2], q, R[3], r[2], u[2], v[2];
+};
+__device__ __forceinline__ void load_stage1(const Consts& K, const Work& W, int b, int i, int g, int k, double mu, double delta_w,
+                                            Stage1Regs& s) {
+  const int N = W.N;
+  const int km = k > 0 ? k - 1 : 0;
+  const double wn = k > 0 ? 1.0 : 0.0;
+  s.a = PG(W.QP, QP_A + i * 8 + g, k, QP_NF);
+  s.bb = PG(W.QP, QP_B + i * 2 + (g & 1), k, QP_NF);
+  s.b = PG(W.QP, QP_b + i, k, QP_NF);
+  const double qa = PG(W.QP, QP_Q + sidx(i, g), k, QP_NF), qb = PG(W.QP, QP_Qx + sidx(i, g), km, QP_NF);
+  s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
+  const double q0 = PG(W.QP, QP_q0 + i, k, QP_NF), q1 = PG(W.QP, QP_q1 + i, k, QP_NF);
+  const double x0 = PG(W.QP, QP_qx0 + i, km, QP_NF), x1 = PG(W.QP, QP_qx1 + i, km, QP_NF);
+  s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
+  const double r00 = PG(W.QP, QP_r0 + 0, k, QP_NF), r01 = PG(W.QP, QP_r0 + 1, k, QP_NF);
+  const double r10 = PG(W.QP, QP_r1 + 0, k, QP_NF), r11 = PG(W.QP, QP_r1 + 1, k, QP_NF);
+  s.u[0] = PL(W.U, 0, k, N), s.u[1] = PL(W.U, 1, k, N);
+  const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
+  const double p0 = W.uprev[b], p1 = W.uprev[(size_t)W.Bp + b];
+  s.q_elem = qa + ((i == g) ? delta_w : 0.0) + wn * qb;
+  s.q = q0 + mu * q1 + wn * (x0 + mu * x1);
+  s.r[0] = r00 + mu * r10, s.r[1] = r01 + mu * r11;
+  s.v[0] = k > 0 ? v0 : p0, s.v[1] = k > 0 ? v1 : p1;
+}
+
+__device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLds& L, const int g, const int i, const int b,
+                                           const bool valid, const int active_slot, const int max_sweeps) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+#define STD(f) st[(size_t)(f) * W.Bp + b]
+#define STI(f) si[(size_t)(f) * W.Bp + b]
+  const ltompc_options& o = K.o;
+  bool live = valid && !STI(SI_DONE);
+  if (!__any(live)) return;
+  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
+  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
+  // than one sweep however hard the worst instance of the batch is.
+  const bool retry = live && STI(SI_RETRY);
+  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
+  //      every lane (identical to the serial kernel, so that both produce the same bits)
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
+  for (int k = i; k < N; k += 8) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+  }
+  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
+  double smult = 0.0, obj;
+  {
+    double x0[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) x0[j] = W.x0[(size_t)j * W.Bp + b];
+    if (!live) x0[3] = 1.0;  // keep atan(vy/vx) finite on padding lanes
+    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
+  }
+  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  int term = -1;
+  if (live && !retry) {
+    int iters = STI(SI_ITERS);
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
+      if (i == 0) STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (i == 0) {
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+    }
+    if (term >= 0) live = false;
+  }
+  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
+  if (!__any(live)) return;
+  // ---- monotone barrier update
+  bool mu_changed = false;
+  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (live && !retry && i == 0) {
+    if (mu_changed) {
+      STD(ST_MU) = mu;
+      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+    }
+    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  }
+  // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
+  //      the others recompute the same numbers)
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  int tries = 0;
+  if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
+  bool numerical = false;
+  // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
+  // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
+  // once only the stragglers are left
+  mu = __shfl(mu, 8 * i);  // the column lanes (g > 0) do real work here: give them the live lane's barrier parameter
+  for (int sweep = 0;; sweep++) {
+    delta_w = __shfl(delta_w, 8 * i);  // ... and its regularisation
+    bool ok = true;
+    double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
+    ppi = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
+    pxv[0] = pxv[1] = 0.0;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (j <= i) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = Prow[j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = ppi;
+    }
+    WAVE_SYNC();
+    L.Pxv[i * 2][0] = 0.0, L.Pxv[i * 2 + 1][0] = 0.0;
+    Stage1Regs cur;
+    load_stage1(K, W, b, i, g, N - 1, mu, delta_w, cur);
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+      Stage1Regs nxt = cur;
+      if (k > 0) load_stage1(K, W, b, i, g, k - 1, mu, delta_w, nxt);
+      const double Rm[3] = {cur.R[0], cur.R[1], cur.R[2]}, rr[2] = {cur.r[0], cur.r[1]};
+      const double uk[2] = {cur.u[0], cur.u[1]}, vk[2] = {cur.v[0], cur.v[1]};
+      WAVE_SYNC();
+      L.A[i * 8 + g][0] = cur.a;
+      if (g < 2) L.B[i * 2 + g][0] = cur.bb;
+      L.b[i][0] = cur.b;
+      WAVE_SYNC();
+      // 1. element (i, g) of P A, element (i, g < 2) of P B, P b + p (same expressions as d_riccati8, one column per lane)
+      double pa = 0.0, pb = 0.0, Pbi = ppi;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        pa += Prow[l] * L.A[l * 8 + g][0];
+        if (g < 2) pb += Prow[l] * L.B[l * 2 + g][0];
+        Pbi += Prow[l] * L.b[l][0];
+      }
+      L.PA[i * 8 + g][0] = pa;
+      if (g < 2) L.PB[i * 2 + g][0] = pb;
+      L.Pb[i][0] = Pbi;
+      WAVE_SYNC();
+      // 2. element (i, g) of Hxx, row i of Hux^T, gx_i
+      double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        double ali = L.A[l * 8 + i][0];
+        hxx += ali * L.PA[l * 8 + g][0];
+        double pali = L.PA[l * 8 + i][0];
+        Hxu[0] += L.B[l * 2][0] * pali + L.Pxv[l * 2][0] * ali;
+        Hxu[1] += L.B[l * 2 + 1][0] * pali + L.Pxv[l * 2 + 1][0] * ali;
+        gx += ali * L.Pb[l][0];
+      }
+      // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles
+      double he = 0.0;
+      if (g < 4) {
+        const int c = g >> 1, d = g & 1;
+        double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
+#pragma unroll
+        for (int l = 0; l < 8; l++)
+          s += L.B[l * 2 + c][0] * L.PB[l * 2 + d][0] + L.B[l * 2 + c][0] * L.Pxv[l * 2 + d][0] + L.Pxv[l * 2 + c][0] * L.B[l * 2 + d][0];
+        he = s;
+        if (c == d) he += r2[c] + delta_w;
+      } else if (g < 6) {
+        const int c = g - 4;
+        double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += L.B[l * 2 + c][0] * L.Pb[l][0] + L.Pxv[l * 2 + c][0] * L.b[l][0];
+        he = s;
+      }
+      double Huu[4], gu[2];
+#pragma unroll
+      for (int q = 0; q < 4; q++) Huu[q] = __shfl(he, q + 8 * i);
+      gu[0] = __shfl(he, 4 + 8 * i), gu[1] = __shfl(he, 5 + 8 * i);
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
+      if (bad && live) ok = false;
+      if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kc[2], Kv[4], kff[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);  // K[c][i]
+        Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
+        kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
+      }
+      L.K[i][0] = Kc[0], L.K[8 + i][0] = Kc[1];
+      WAVE_SYNC();
+      // 4. cost-to-go: element (i, g)
+      const double pn = hxx + Hxu[0] * L.K[g][0] + Hxu[1] * L.K[8 + g][0];
+      pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
+      ppi = gx + Hxu[0] * kff[0] + Hxu[1] * kff[1];
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) Pvv[c * 2 + d] = ((c == d) ? r2[c] : 0.0) - r2[c] * Kv[c * 2 + d];
+        pv[c] = gv[c] - r2[c] * kff[c];
+      }
+      L.P[i * 8 + g][0] = pn;
+      WAVE_SYNC();
+#pragma unroll
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? L.P[i * 8 + j][0] : 0.5 * (L.P[i * 8 + j][0] + L.P[j * 8 + i][0]);
+      L.Pxv[i * 2][0] = pxv[0], L.Pxv[i * 2 + 1][0] = pxv[1];
+      if (live) {
+        PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        if (k > 0) {
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (j <= i) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = Prow[j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = pxv[0], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = pxv[1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
+        }
+      }
+      cur = nxt;
+    }
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
+    const bool failed = live && !ok;
+    if (failed) {
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+      if (++tries > 40 || delta_w > 1e20) numerical = true;
+      if (i == 0) STI(SI_NREG) += 1;
+    }
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    if (failed && !again) {  // continue in the next launch (or give up)
+      if (i == 0) {
+        STI(SI_STEP) = 0;
+        if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+        else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = delta_w;
+      }
+      live = false;
+    }
+    if (!__any(again)) break;
+  }
+  if (live && i == 0) {
+    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+    STD(ST_DW) = delta_w;
+    STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
+    STI(SI_STEP) = 1;
+  }
+  if (!__any(live)) return;
+  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
+  double dxi = 0.0, dv[2] = {0.0, 0.0};
+  if (live) PL(W.dX, i, 0, N + 1) = 0.0;
+  FwdRegs fc;
+  load_fwd(W, b, i, 0, fc);
+#pragma unroll 1
+  for (int k = 0; k < N; k++) {
+    FwdRegs fn = fc;
+    if (k + 1 < N) load_fwd(W, b, i, k + 1, fn);
+    double dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
+    double du[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double s = fc.kff[c] + fc.Kv[c * 2] * dv[0] + fc.Kv[c * 2 + 1] * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += fc.K[c * 8 + j] * dx[j];
+      du[c] = s;
+    }
+    double s = fc.b + fc.B[0] * du[0] + fc.B[1] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += fc.A[j] * dx[j];
+    dxi = s;
+    dv[0] = du[0], dv[1] = du[1];
+    if (live) {
+      PL(W.dX, i, k + 1, N + 1) = dxi;
+      if (i < 2) PL(W.dU, i, k, N) = du[i];
+    }
+    fc = fn;
+  }
+#undef STD
+#undef STI
+}
+
 __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index, int max_sweeps) {
   __shared__ RicLds L;
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
@@ -1525,7 +1828,7 @@ __global__ void __launch_bounds__(64) k_tail(Consts K, Work W, int max_passes) {
     if (PH(1))
       for (int k = lane; k < N; k += 64) d_eval(K, W, k, b);
     __syncthreads();
-    if (PH(2)) d_riccati8(K, W, L, g, i, b, g == 0, -1, 8);
+    if (PH(2)) d_riccati1(K, W, L, g, i, b, g == 0, -1, 8);
     __syncthreads();
     if (si[(size_t)SI_DONE * W.Bp + b]) break;
     if (si[(size_t)SI_STEP * W.Bp + b]) {
@@ -1588,6 +1891,7 @@ __global__ void k_load_x0(Work W, const double* __restrict__ x0_rm) {
   if (b >= W.B) return;
 #pragma unroll
   for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[(size_t)b * 8 + i];
+  W.si[(size_t)SI_PREV * W.Bp + b] = W.si[(size_t)SI_STATUS * W.Bp + b];  // k_init resets the rest
 }
 __global__ void k_zero_uprev(Work W) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;

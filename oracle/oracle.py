@@ -29,7 +29,7 @@ class Options(C.Structure):
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
         "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -115,11 +115,37 @@ class Oracle:
         return xn
 
     # ---- NLP solve ----------------------------------------------------------------
-    def solve(self, x0, N, uprev=None, warm=None, nthreads=0):
+    def solve(self, x0, N, uprev=None, warm=None, nthreads=0, prev_status=None):
         """x0: (B,8).  warm: dict(X,C,U,L1,L2) of a previous solve or None (do_mpc set_initial_guess).
+        prev_status: status of the solve `warm` comes from (option warm_reset_on_fail of include/ltompc.h: an instance
+        whose previous solve did not converge keeps the primal point, restarts L1 = L2 = 0 and the barrier at mu_init).
         Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail)."""
         x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
         B = x0.shape[0]
+        if warm is not None and prev_status is not None and self.o.warm_reset_on_fail:
+            bad = ~np.isin(np.asarray(prev_status).reshape(B), (0, 1))
+            if bad.any():
+                up = np.zeros((B, 2)) if uprev is None else np.atleast_2d(uprev)
+                parts = []
+                for sel, reset in ((~bad, False), (bad, True)):
+                    if not sel.any():
+                        parts.append(None); continue
+                    w = {k: np.array(warm[k][sel], float) for k in ("X", "C", "U", "L1", "L2")}
+                    saved = self.o.mu_init_warm
+                    if reset:
+                        w["L1"][:] = 0.0; w["L2"][:] = 0.0; self.o.mu_init_warm = 0.0
+                    try:
+                        parts.append(self.solve(x0[sel], N, up[sel], w, nthreads))
+                    finally:
+                        self.o.mu_init_warm = saved
+                out = {}
+                ref = parts[0] or parts[1]
+                for k, v in ref.items():
+                    out[k] = np.zeros((B,) + v.shape[1:], v.dtype)
+                    for sel, part in zip((~bad, bad), parts):
+                        if part is not None:
+                            out[k][sel] = part[k]
+                return out
         uprev = np.zeros((B, 2)) if uprev is None else np.ascontiguousarray(np.atleast_2d(uprev), float)
         if warm is None:
             X, Cc, U = np.zeros((B, N + 1, 8)), np.zeros((B, N, 8)), np.zeros((B, N, 2))

@@ -68,7 +68,7 @@ def test_batch_cold_and_warm_ticks(pkg, tables, oracle, gpu_lib):
     uprev = np.zeros((B, 2))
     for tick in range(3):
         u0 = mpc.make_step(x0)
-        ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8)
+        ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (mpc.status == 0) & (ref["status"] == 0)
         assert both.mean() > 0.9, (tick, both.mean())
         err = np.abs(u0 - ref["u0"])[both].max()
@@ -201,7 +201,7 @@ def test_warm_start_options_match_oracle(pkg, tables, orc, gpu_lib):
     base_iters = None
     for tick in range(4):
         u0 = mpc.make_step(x0)
-        ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8)
+        ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (mpc.status == 0) & (ref["status"] == 0)
         assert both.mean() > 0.85, (tick, both.mean())
         assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, tick
