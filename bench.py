@@ -30,8 +30,24 @@ BYTES_PER_STAGE_ITER = 8 * (2 * WORDS_QP + WORDS_RIC_OUT + WORDS_EVAL_IN)  # 310
 BYTES_BY_KERNEL = {  # share of the 3104 B each kernel class moves (algorithmic, not measured traffic)
     "eval": 8 * (WORDS_QP + WORDS_EVAL_IN), "riccati": 8 * (WORDS_QP + WORDS_RIC_OUT),
     "expand": 8 * (WORDS_EVAL_IN + WORDS_RIC_OUT), "linesearch": 8 * WORDS_EVAL_IN, "pick": 0, "update": 8 * 2 * WORDS_EVAL_IN,
-    "tail": 0,  # straggler kernel: latency-bound by construction, no roofline claim
+    "riccati1": 0,  # one-wavefront-per-instance sweep of the narrow launches: latency-bound by construction, no roofline claim
 }
+
+
+def load_pmc_traffic(kernel, B, N):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (separate rocprofv3 --pmc
+    passes, profiles/pmc_traffic.py); None when there is none for this batch / horizon."""
+    import glob
+    import json as _json
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_traffic.json")), reverse=True):
+        try:
+            d = _json.load(open(f))
+        except Exception:
+            continue
+        k = d.get("kernels", {}).get("k_" + kernel)
+        if k and d.get("batch") == B and d.get("horizon") == N:
+            return dict(k, source=os.path.relpath(f, ROOT))
+    return None
 
 
 def main():
@@ -108,6 +124,7 @@ def main():
     elapsed = t1 - t0
     st = mpc.stats()  # last tick
     tm = mpc.timing()
+    log = mpc.launch_log() if not args.no_profile else None
     mpc.set_profiling(False)
 
     if world > 1:
@@ -137,6 +154,27 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": bytes_per_launch,
                     "kernel_ms_total": {k: round(v, 3) for k, v in ms.items()}, "launches": ln}
+        # the same kernel over its full-width launches only (every instance of the batch still iterating or idle in
+        # its wavefront; the launches after the first re-packing are sized for a few stragglers and latency-bound)
+        pmc = load_pmc_traffic(dom, B, N)
+        if pmc:
+            roofline["traffic"] = pmc["traffic_avg_all_launches"]
+            roofline["traffic_source"] = pmc["source"]
+        names = list(ms.keys())
+        kind, width, lms = log
+        full = (kind == names.index(dom)) & (width == B)
+        if full.any():
+            fw_ms = float(lms[full].mean())
+            fw_bytes = B * N * BYTES_BY_KERNEL[dom]
+            roofline["full_width"] = {"launches": int(full.sum()), "avg_launch_ms": fw_ms, "algorithmic_bytes_per_launch": fw_bytes,
+                                      "achieved": fw_bytes / (fw_ms * 1e-3) / 1e9, "frac": fw_bytes / (fw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            by_width = {}
+            for w in sorted(set(int(x) for x in width[kind == names.index(dom)]), reverse=True)[:12]:
+                sel = (kind == names.index(dom)) & (width == w)
+                by_width[str(w)] = [int(sel.sum()), round(float(lms[sel].mean()), 4)]
+            roofline["avg_launch_ms_by_width"] = by_width  # width -> [launches, avg ms]
+            if pmc:
+                roofline["full_width"]["traffic"] = pmc["traffic"]
 
     # ---- batch = 1 latency (second handle, same stream), reported as an extra
     extras = {}

@@ -167,12 +167,17 @@ int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:
- * index 0 eval, 1 riccati, 2 expand, 3 linesearch, 4 pick, 5 update, 6 tail (the one-wavefront-per-instance kernel that
- * finishes the stragglers).  launches / ip_iterations (wide iterations launched) refer to the last make_step.
+ * index 0 eval, 1 riccati (8 instances per wavefront), 2 expand, 3 linesearch, 4 pick, 5 update, 6 riccati1 (the
+ * one-wavefront-per-instance sweep used once few instances are left).  launches / ip_iterations (iterations launched)
+ * refer to the last make_step.
  * Arrays have 7 entries.  Any output may be NULL. */
 int ltompc_set_profiling(ltompc_handle h, int on);
 int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_kernel7, int* launches,
                       int* ip_iterations);
+/* Per-launch log of the profiled make_steps since profiling was switched on: kernel class (index as above), launch
+ * width (instances the launch was sized for: the whole batch until the first re-packing of the unfinished instances)
+ * and device time in ms.  Returns the number of log entries (copies at most `capacity`); negative on error. */
+int ltompc_get_launch_log(ltompc_handle h, int* kind, int* width, double* ms, int capacity);
 
 /* Poll history of the last make_step: up to `capacity` triples (iteration, unfinished instances, launch width);
  * returns the number of polls (>= 0). */

@@ -1150,37 +1150,49 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
 #undef STI
 }
 
-// ---- single-instance form of the sweep (k_tail): all 64 lanes work on ONE instance, lane (g, i) computes column g of
+// ---- single-instance form of the sweep (k_riccati1): all 64 lanes work on ONE instance, lane (g, i) computes column g of
 // row i of the 8x8 products instead of all 8 columns, with the SAME per-element expressions as d_riccati8, so that the
 // bits do not depend on which of the two a solve goes through.  LDS slot [field][0] is shared by the 8 column lanes.
 struct Stage1Regs {
   double a, bb, b, q_elem, S[2], q, R[3], r[2], u[2], v[2];
 };
-__device__ __forceinline__ void load_stage1(const Consts& K, const Work& W, int b, int i, int g, int k, double mu, double delta_w,
-                                            Stage1Regs& s) {
-  const int N = W.N;
+// Stage data of the ONE instance of a k_riccati1 block, staged in LDS once per launch: with a single wavefront per
+// instance the sweep is a chain of N dependent stages, and fetching each stage from HBM/L2 (even one stage ahead) costs
+// more than the stage's arithmetic.  q: [N][QP_NF] (copy of the instance's QP blocks), u: [N][2], kk: [N][22] gains.
+struct StageLds {  // views into the dynamic LDS of a k_riccati1 block
+  double* q;   // [N][QP_NF]
+  double* u;   // [N][2]
+  double* kk;  // [N][22]
+};
+struct Ric1Lds {
+  double PA[64], PB[16], Pb[8], K[16], P[64], Pxv[16];
+};
+__host__ __device__ constexpr size_t ric1_lds_bytes(int N) { return sizeof(double) * (size_t)N * (QP_NF + 24) + sizeof(Ric1Lds); }
+__device__ __forceinline__ void load_stage1(const StageLds& S, const double p0, const double p1, int i, int g, int k, double mu,
+                                            double delta_w, Stage1Regs& s) {
   const int km = k > 0 ? k - 1 : 0;
   const double wn = k > 0 ? 1.0 : 0.0;
-  s.a = PG(W.QP, QP_A + i * 8 + g, k, QP_NF);
-  s.bb = PG(W.QP, QP_B + i * 2 + (g & 1), k, QP_NF);
-  s.b = PG(W.QP, QP_b + i, k, QP_NF);
-  const double qa = PG(W.QP, QP_Q + sidx(i, g), k, QP_NF), qb = PG(W.QP, QP_Qx + sidx(i, g), km, QP_NF);
-  s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
-  const double q0 = PG(W.QP, QP_q0 + i, k, QP_NF), q1 = PG(W.QP, QP_q1 + i, k, QP_NF);
-  const double x0 = PG(W.QP, QP_qx0 + i, km, QP_NF), x1 = PG(W.QP, QP_qx1 + i, km, QP_NF);
-  s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
-  const double r00 = PG(W.QP, QP_r0 + 0, k, QP_NF), r01 = PG(W.QP, QP_r0 + 1, k, QP_NF);
-  const double r10 = PG(W.QP, QP_r1 + 0, k, QP_NF), r11 = PG(W.QP, QP_r1 + 1, k, QP_NF);
-  s.u[0] = PL(W.U, 0, k, N), s.u[1] = PL(W.U, 1, k, N);
-  const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
-  const double p0 = W.uprev[b], p1 = W.uprev[(size_t)W.Bp + b];
+  const double* q = S.q + k * QP_NF;
+  const double* qm = S.q + km * QP_NF;
+  s.a = q[QP_A + i * 8 + g];
+  s.bb = q[QP_B + i * 2 + (g & 1)];
+  s.b = q[QP_b + i];
+  const double qa = q[QP_Q + sidx(i, g)], qb = qm[QP_Qx + sidx(i, g)];
+  s.S[0] = q[QP_S + i], s.S[1] = q[QP_S + 8 + i];
+  const double q0 = q[QP_q0 + i], q1 = q[QP_q1 + i];
+  const double x0 = qm[QP_qx0 + i], x1 = qm[QP_qx1 + i];
+  s.R[0] = q[QP_R + 0], s.R[1] = q[QP_R + 1], s.R[2] = q[QP_R + 2];
+  const double r00 = q[QP_r0 + 0], r01 = q[QP_r0 + 1];
+  const double r10 = q[QP_r1 + 0], r11 = q[QP_r1 + 1];
+  s.u[0] = S.u[k * 2], s.u[1] = S.u[k * 2 + 1];
+  const double v0 = S.u[km * 2], v1 = S.u[km * 2 + 1];
   s.q_elem = qa + ((i == g) ? delta_w : 0.0) + wn * qb;
   s.q = q0 + mu * q1 + wn * (x0 + mu * x1);
   s.r[0] = r00 + mu * r10, s.r[1] = r01 + mu * r11;
   s.v[0] = k > 0 ? v0 : p0, s.v[1] = k > 0 ? v1 : p1;
 }
 
-__device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLds& L, const int g, const int i, const int b,
+__device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1Lds& L, const StageLds& S, const int g, const int i, const int b,
                                            const bool valid, const int active_slot, const int max_sweeps) {
   const int N = W.N;
   double* st = W.st;
@@ -1188,6 +1200,10 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
 #define STD(f) st[(size_t)(f) * W.Bp + b]
 #define STI(f) si[(size_t)(f) * W.Bp + b]
   const ltompc_options& o = K.o;
+  // LTOMPC_DBG: shader-clock cycles of block 0 per section (head, staging, backward sweeps, forward), summed over launches
+  const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  long long rt0 = rprof ? clock64() : 0;
+#define RTOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
   bool live = valid && !STI(SI_DONE);
   if (!__any(live)) return;
   // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
@@ -1264,14 +1280,37 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
   // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
   // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
   // once only the stragglers are left
+  RTOCK(0);
+  // stage the instance's QP blocks and inputs in LDS (all 64 lanes, independent loads)
+  {
+    const int lane = i * 8 + g;
+    const int total = N * QP_NF;
+    for (int base = lane; base < total; base += 64 * 8) {  // 8 independent loads in flight per lane
+      double v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int idx = base + 64 * r, ic = idx < total ? idx : total - 1;
+        const int kq = ic / QP_NF, fq = ic - kq * QP_NF;
+        v[r] = PG(W.QP, fq, kq, QP_NF);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        if (base + 64 * r < total) S.q[base + 64 * r] = v[r];
+    }
+    for (int idx = lane; idx < N * 2; idx += 64) S.u[idx] = PL(W.U, idx & 1, idx >> 1, N);
+  }
+  WAVE_SYNC();
+  RTOCK(1);
+  // (read once: a global load inside the stage loop would wait, on vmcnt, for the RC stores of the previous stage)
+  const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
   mu = __shfl(mu, 8 * i);  // the column lanes (g > 0) do real work here: give them the live lane's barrier parameter
   for (int sweep = 0;; sweep++) {
     delta_w = __shfl(delta_w, 8 * i);  // ... and its regularisation
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
-    ppi = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
+    for (int j = 0; j < 8; j++) Prow[j] = S.q[(N - 1) * QP_NF + QP_Qx + sidx(i, j)] + ((i == j) ? delta_w : 0.0);
+    ppi = S.q[(N - 1) * QP_NF + QP_qx0 + i] + mu * S.q[(N - 1) * QP_NF + QP_qx1 + i];
     pxv[0] = pxv[1] = 0.0;
     if (live) {
 #pragma unroll
@@ -1281,58 +1320,56 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
       PG(W.RC, RC_pp + i, N, RC_NF) = ppi;
     }
     WAVE_SYNC();
-    L.Pxv[i * 2][0] = 0.0, L.Pxv[i * 2 + 1][0] = 0.0;
-    Stage1Regs cur;
-    load_stage1(K, W, b, i, g, N - 1, mu, delta_w, cur);
+    L.Pxv[i * 2] = 0.0, L.Pxv[i * 2 + 1] = 0.0;
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
-      Stage1Regs nxt = cur;
-      if (k > 0) load_stage1(K, W, b, i, g, k - 1, mu, delta_w, nxt);
+      Stage1Regs cur;
+      load_stage1(S, up0, up1, i, g, k, mu, delta_w, cur);
       const double Rm[3] = {cur.R[0], cur.R[1], cur.R[2]}, rr[2] = {cur.r[0], cur.r[1]};
       const double uk[2] = {cur.u[0], cur.u[1]}, vk[2] = {cur.v[0], cur.v[1]};
-      WAVE_SYNC();
-      L.A[i * 8 + g][0] = cur.a;
-      if (g < 2) L.B[i * 2 + g][0] = cur.bb;
-      L.b[i][0] = cur.b;
-      WAVE_SYNC();
+      const double* qk = S.q + k * QP_NF;  // A_k, B_k, b_k are read in place
       // 1. element (i, g) of P A, element (i, g < 2) of P B, P b + p (same expressions as d_riccati8, one column per lane)
       double pa = 0.0, pb = 0.0, Pbi = ppi;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        pa += Prow[l] * L.A[l * 8 + g][0];
-        if (g < 2) pb += Prow[l] * L.B[l * 2 + g][0];
-        Pbi += Prow[l] * L.b[l][0];
+        pa += Prow[l] * qk[QP_A + l * 8 + g];
+        if (g < 2) pb += Prow[l] * qk[QP_B + l * 2 + g];
+        Pbi += Prow[l] * qk[QP_b + l];
       }
-      L.PA[i * 8 + g][0] = pa;
-      if (g < 2) L.PB[i * 2 + g][0] = pb;
-      L.Pb[i][0] = Pbi;
+      L.PA[i * 8 + g] = pa;
+      if (g < 2) L.PB[i * 2 + g] = pb;
+      L.Pb[i] = Pbi;
       WAVE_SYNC();
       // 2. element (i, g) of Hxx, row i of Hux^T, gx_i
       double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        double ali = L.A[l * 8 + i][0];
-        hxx += ali * L.PA[l * 8 + g][0];
-        double pali = L.PA[l * 8 + i][0];
-        Hxu[0] += L.B[l * 2][0] * pali + L.Pxv[l * 2][0] * ali;
-        Hxu[1] += L.B[l * 2 + 1][0] * pali + L.Pxv[l * 2 + 1][0] * ali;
-        gx += ali * L.Pb[l][0];
+        double ali = qk[QP_A + l * 8 + i];
+        hxx += ali * L.PA[l * 8 + g];
+        double pali = L.PA[l * 8 + i];
+        Hxu[0] += qk[QP_B + l * 2] * pali + L.Pxv[l * 2] * ali;
+        Hxu[1] += qk[QP_B + l * 2 + 1] * pali + L.Pxv[l * 2 + 1] * ali;
+        gx += ali * L.Pb[l];
       }
       // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles
+      // (selects instead of run-time indices into the small arrays: an indexed array lives in scratch, and on gfx9 a
+      //  scratch reload waits on vmcnt, i.e. for every RC store of the previous stage to be acknowledged)
       double he = 0.0;
       if (g < 4) {
         const int c = g >> 1, d = g & 1;
-        double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
+        const double rm = (c + d == 0) ? Rm[0] : ((c + d == 1) ? Rm[1] : Rm[2]);  // Rm[sidx(c, d)]
+        const double pvv = c ? (d ? Pvv[3] : Pvv[2]) : (d ? Pvv[1] : Pvv[0]);     // Pvv[c * 2 + d]
+        double s = rm + pvv;
 #pragma unroll
         for (int l = 0; l < 8; l++)
-          s += L.B[l * 2 + c][0] * L.PB[l * 2 + d][0] + L.B[l * 2 + c][0] * L.Pxv[l * 2 + d][0] + L.Pxv[l * 2 + c][0] * L.B[l * 2 + d][0];
+          s += qk[QP_B + l * 2 + c] * L.PB[l * 2 + d] + qk[QP_B + l * 2 + c] * L.Pxv[l * 2 + d] + L.Pxv[l * 2 + c] * qk[QP_B + l * 2 + d];
         he = s;
-        if (c == d) he += r2[c] + delta_w;
+        if (c == d) he += (c ? r2[1] : r2[0]) + delta_w;
       } else if (g < 6) {
         const int c = g - 4;
-        double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
+        double s = (c ? rr[1] : rr[0]) + (c ? r2[1] : r2[0]) * ((c ? uk[1] : uk[0]) - (c ? vk[1] : vk[0])) + (c ? pv[1] : pv[0]);
 #pragma unroll
-        for (int l = 0; l < 8; l++) s += L.B[l * 2 + c][0] * L.Pb[l][0] + L.Pxv[l * 2 + c][0] * L.b[l][0];
+        for (int l = 0; l < 8; l++) s += qk[QP_B + l * 2 + c] * L.Pb[l] + L.Pxv[l * 2 + c] * qk[QP_b + l];
         he = s;
       }
       double Huu[4], gu[2];
@@ -1351,10 +1388,10 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
         Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
         kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
       }
-      L.K[i][0] = Kc[0], L.K[8 + i][0] = Kc[1];
+      L.K[i] = Kc[0], L.K[8 + i] = Kc[1];
       WAVE_SYNC();
       // 4. cost-to-go: element (i, g)
-      const double pn = hxx + Hxu[0] * L.K[g][0] + Hxu[1] * L.K[8 + g][0];
+      const double pn = hxx + Hxu[0] * L.K[g] + Hxu[1] * L.K[8 + g];
       pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
       ppi = gx + Hxu[0] * kff[0] + Hxu[1] * kff[1];
       double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
@@ -1364,11 +1401,16 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
         for (int d = 0; d < 2; d++) Pvv[c * 2 + d] = ((c == d) ? r2[c] : 0.0) - r2[c] * Kv[c * 2 + d];
         pv[c] = gv[c] - r2[c] * kff[c];
       }
-      L.P[i * 8 + g][0] = pn;
+      L.P[i * 8 + g] = pn;
       WAVE_SYNC();
 #pragma unroll
-      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? L.P[i * 8 + j][0] : 0.5 * (L.P[i * 8 + j][0] + L.P[j * 8 + i][0]);
-      L.Pxv[i * 2][0] = pxv[0], L.Pxv[i * 2 + 1][0] = pxv[1];
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? L.P[i * 8 + j] : 0.5 * (L.P[i * 8 + j] + L.P[j * 8 + i]);
+      L.Pxv[i * 2] = pxv[0], L.Pxv[i * 2 + 1] = pxv[1];
+      if (g == 0) {  // the gains stay in LDS for the forward rollout (same numbers in all column lanes)
+        S.kk[k * 22 + i] = Kc[0], S.kk[k * 22 + 8 + i] = Kc[1];
+        if (i < 4) S.kk[k * 22 + 16 + i] = Kv[i];
+        if (i < 2) S.kk[k * 22 + 20 + i] = kff[i];
+      }
       if (live) {
         PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
         if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
@@ -1381,7 +1423,6 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
           PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
         }
       }
-      cur = nxt;
     }
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
     const bool failed = live && !ok;
@@ -1402,6 +1443,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
     }
     if (!__any(again)) break;
   }
+  RTOCK(2);
   if (live && i == 0) {
     STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
     STD(ST_DW) = delta_w;
@@ -1412,12 +1454,19 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
   // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
   double dxi = 0.0, dv[2] = {0.0, 0.0};
   if (live) PL(W.dX, i, 0, N + 1) = 0.0;
-  FwdRegs fc;
-  load_fwd(W, b, i, 0, fc);
+  WAVE_SYNC();
 #pragma unroll 1
   for (int k = 0; k < N; k++) {
-    FwdRegs fn = fc;
-    if (k + 1 < N) load_fwd(W, b, i, k + 1, fn);
+    FwdRegs fc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) fc.K[j] = S.kk[k * 22 + j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fc.Kv[j] = S.kk[k * 22 + 16 + j];
+    fc.kff[0] = S.kk[k * 22 + 20], fc.kff[1] = S.kk[k * 22 + 21];
+#pragma unroll
+    for (int j = 0; j < 8; j++) fc.A[j] = S.q[k * QP_NF + QP_A + i * 8 + j];
+    fc.B[0] = S.q[k * QP_NF + QP_B + i * 2], fc.B[1] = S.q[k * QP_NF + QP_B + i * 2 + 1];
+    fc.b = S.q[k * QP_NF + QP_b + i];
     double dx[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
@@ -1438,8 +1487,10 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, RicLd
       PL(W.dX, i, k + 1, N + 1) = dxi;
       if (i < 2) PL(W.dU, i, k, N) = du[i];
     }
-    fc = fn;
   }
+  RTOCK(3);
+  if (rprof) W.DBG[4] += 1.0;
+#undef RTOCK
 #undef STD
 #undef STI
 }
@@ -1450,6 +1501,18 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index,
   const int jj = blockIdx.x * 8 + g;
   const bool valid = jj < W.nact[0];
   d_riccati8(K, W, L, g, i, W.act[valid ? jj : 0], valid, it_index, max_sweeps);
+}
+
+// One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
+// sweep, and 8 instances per wavefront make that sweep ~3x longer than it has to be).  Dynamic LDS: ric1_lds_bytes(N).
+__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, int it_index) {
+  extern __shared__ double lds1[];
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  if ((int)blockIdx.x >= W.nact[0]) return;
+  const int N = W.N;
+  StageLds S{lds1, lds1 + (size_t)N * QP_NF, lds1 + (size_t)N * (QP_NF + 2)};
+  Ric1Lds& L = *reinterpret_cast<Ric1Lds*>(lds1 + (size_t)N * (QP_NF + 24));
+  d_riccati1(K, W, L, S, g, i, W.act[blockIdx.x], g == 0, it_index, 1);
 }
 
 // ------------------------------------------------------------------------------------------ k_expand
@@ -1806,53 +1869,6 @@ __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
   d_update(K, W, k, W.act[j]);
 }
 
-// ------------------------------------------------------------------------------------------ k_tail
-// The stragglers: one wavefront per unfinished instance runs the WHOLE remaining interior-point loop in one launch
-// (lane = interval for the interval-parallel phases, lanes g == 0 for the 8-lane Riccati / pick phases).  The wide
-// launches above are efficient while thousands of instances iterate in lock-step; the last <1% of the instances need
-// 40..150 iterations, and at that width every kernel of the sequence is pure launch + single-wave latency (~0.8 ms per
-// iteration, two thirds of a tick).  Here each straggler proceeds at its own pace, with no launch in between and
-// with the regularisation retries inside the iteration (exactly the oracle's iteration semantics).
-__global__ void __launch_bounds__(64) k_tail(Consts K, Work W, int max_passes) {
-  __shared__ RicLds L;
-  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  if ((int)blockIdx.x >= W.nact[0]) return;
-  const int b = W.act[blockIdx.x];
-  const int N = W.N;
-  const int* si = W.si;
-  const int dbg = W.debug_extra_sweeps & 255;  // bisecting aid: bit mask of the phases to run (0 = all), passes in bits 8..
-#define PH(bit) (dbg == 0 || (dbg & (bit)))
-  if (W.debug_extra_sweeps >> 8) max_passes = W.debug_extra_sweeps >> 8;
-  for (int pass = 0; pass < max_passes; pass++) {
-    if (si[(size_t)SI_DONE * W.Bp + b]) break;  // block-uniform: one instance per block
-    if (PH(1))
-      for (int k = lane; k < N; k += 64) d_eval(K, W, k, b);
-    __syncthreads();
-    if (PH(2)) d_riccati1(K, W, L, g, i, b, g == 0, -1, 8);
-    __syncthreads();
-    if (si[(size_t)SI_DONE * W.Bp + b]) break;
-    if (si[(size_t)SI_STEP * W.Bp + b]) {
-      if (PH(4))
-        for (int k = lane; k < N; k += 64) d_expand(K, W, k, b);
-      __syncthreads();
-      if (PH(8))
-        for (int k = lane; k < N; k += 64) d_linesearch(K, W, k, b, 1, 1);
-      __syncthreads();
-      if (PH(16) && g == 0) d_pick(K, W, b, i, 0, false);
-      __syncthreads();
-      if (PH(32) && si[(size_t)SI_LSMORE * W.Bp + b]) {
-        for (int k = lane; k < N; k += 64) d_linesearch(K, W, k, b, 2, K.o.n_linesearch);
-        __syncthreads();
-        if (g == 0) d_pick(K, W, b, i, 1, false);
-        __syncthreads();
-      }
-      if (PH(64))
-        for (int k = lane; k < N; k += 64) d_update(K, W, k, b);
-      __syncthreads();
-    }
-  }
-#undef PH
-}
 
 // ------------------------------------------------------------------------------------------ compaction
 __global__ void k_act_identity(int* act, int* nact, int B) {

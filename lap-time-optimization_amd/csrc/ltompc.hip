@@ -28,7 +28,7 @@ int fail(const std::string& msg) {
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
   } while (0)
 
-constexpr int NKERN = 7;  // eval, riccati, expand, linesearch, pick, update, tail
+constexpr int NKERN = 7;  // eval, riccati, expand, linesearch, pick, update, riccati1
 
 }  // namespace
 
@@ -52,11 +52,13 @@ struct ltompc_solver {
   bool compaction = true;       // LTOMPC_COMPACT=0 switches the re-packing of unfinished instances off
   bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
   std::vector<hipEvent_t> ev;  // pairs
-  std::vector<int> ev_kind;
+  std::vector<int> ev_kind, ev_width;
+  std::vector<int> log_kind, log_width;  // per launch of the profiled make_steps since profiling was switched on
+  std::vector<double> log_ms;
+  int cur_width = 0;  // instances in the launches being issued
   double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
   int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
-  int tail_width = 1024;  // LTOMPC_TAIL: switch to one-wavefront-per-instance mode at this many unfinished instances (0 = never)
-  int last_tail_instances = 0;
+  int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
   template <typename T>
@@ -90,18 +92,21 @@ void build_bounds(const ltompc_params& p, Bounds& b) {
 struct Launcher {
   ltompc_solver* h;
   int launches = 0;
+  size_t lds = 0;  // dynamic LDS bytes of the next launch (reset after it)
   template <typename Kern, typename... Args>
   int run(int kind, Kern kern, int threads_total, Args... args) {
     dim3 block(64), grid((threads_total + 63) / 64);
+    const size_t lds_bytes = lds;
+    lds = 0;
     if (h->profiling) {
       hipEvent_t a, b;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail("hipEventCreate failed");
       hipEventRecord(a, h->stream);
-      hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+      hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
       hipEventRecord(b, h->stream);
-      h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(kind);
+      h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(kind), h->ev_width.push_back(h->cur_width);
     } else {
-      hipLaunchKernelGGL(kern, grid, block, 0, h->stream, args...);
+      hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
     }
     launches++;
     return 0;
@@ -114,9 +119,10 @@ int collect_profile(ltompc_solver* h) {
     HIPCHECK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
     h->ms_by_kernel[h->ev_kind[i]] += ms;
     h->launches_by_kernel[h->ev_kind[i]] += 1;
+    h->log_kind.push_back(h->ev_kind[i]), h->log_width.push_back(h->ev_width[i]), h->log_ms.push_back(ms);
     hipEventDestroy(h->ev[2 * i]), hipEventDestroy(h->ev[2 * i + 1]);
   }
-  h->ev.clear(), h->ev_kind.clear();
+  h->ev.clear(), h->ev_kind.clear(), h->ev_width.clear();
   return 0;
 }
 
@@ -202,8 +208,15 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->serial_riccati = e && std::string(e) == "serial";
     const char* c = getenv("LTOMPC_COMPACT");
     h->compaction = !(c && std::string(c) == "0");
-    const char* t = getenv("LTOMPC_TAIL");
-    if (t) h->tail_width = atoi(t);
+    const char* t = getenv("LTOMPC_RIC1");
+    if (t) h->ric1_width = atoi(t);
+    // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
+    if (ric1_lds_bytes(n_horizon) > 150 * 1024) h->ric1_width = 0;
+    else if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_riccati1), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)ric1_lds_bytes(n_horizon)) != hipSuccess) {
+      (void)hipGetLastError();
+      h->ric1_width = 0;
+    }
   }
   const size_t N = h->N, Bp = h->Bp;
   const int ni = h->K.bd.ni;
@@ -269,6 +282,7 @@ int ltompc_set_profiling(ltompc_handle h, int on) {
   if (!h) return fail("null handle");
   h->profiling = on != 0;
   for (int i = 0; i < NKERN; i++) h->ms_by_kernel[i] = 0, h->launches_by_kernel[i] = 0;
+  h->log_kind.clear(), h->log_width.clear(), h->log_ms.clear();
   return 0;
 }
 
@@ -324,11 +338,11 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   }
   auto set_launch = [&](int n) {
     n_launch = n;
+    h->cur_width = n;
     W.act = h->d_act[cur], W.nact = h->d_nact[cur], W.n_launch = n, W.n_pad = (n + 63) / 64 * 64;
   };
   set_launch(B);
   h->last_compactions = 0;
-  h->last_tail_instances = 0;
   h->history.clear();
   int it = 0;
   for (;; it++) {
@@ -340,7 +354,10 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       // measured: letting the stragglers retry inside a launch (max_sweeps 4 when n_launch <= 256) finishes them in
       // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
       const int max_sweeps = 1;
-      if (L.run(1, k_riccati8, np * 8, h->K, W, it, max_sweeps)) return -1;  // 8 lanes per instance
+      if (n_launch <= h->ric1_width) {
+        L.lds = ric1_lds_bytes(N);
+        if (L.run(6, k_riccati1, n_launch * 64, h->K, W, it)) return -1;  // one wavefront per instance
+      } else if (L.run(1, k_riccati8, np * 8, h->K, W, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
     if (L.run(2, k_expand, N * np, h->K, W)) return -1;
@@ -358,30 +375,6 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
       h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
-      if (h->compaction && !h->serial_riccati && n_active <= h->tail_width) {
-        // few instances left: re-pack and let each of them run its remaining iterations in one launch
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
-                           h->W.si + (size_t)SI_DONE * Bp, h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
-        cur ^= 1;
-        set_launch(n_active);
-        h->last_compactions++;
-        h->last_tail_instances = n_active;
-        dim3 grid(n_active), block(64);
-        const int max_passes = 4 * h->max_iter + 64;  // passes that repeat a sweep or a line search do not count as iterations
-        if (h->profiling) {
-          hipEvent_t a, b;
-          if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail("hipEventCreate failed");
-          hipEventRecord(a, h->stream);
-          hipLaunchKernelGGL(k_tail, grid, block, 0, h->stream, h->K, W, max_passes);
-          hipEventRecord(b, h->stream);
-          h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(6);
-        } else {
-          hipLaunchKernelGGL(k_tail, grid, block, 0, h->stream, h->K, W, max_passes);
-        }
-        L.launches++;
-        it++;
-        break;
-      }
       if (h->compaction && n_active <= (3 * n_launch) / 4) {
         // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack the list
         hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
@@ -518,6 +511,17 @@ int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_k
   if (launches) *launches = h->last_launches;
   if (ip_iterations) *ip_iterations = h->last_iterations;
   return 0;
+}
+
+int ltompc_get_launch_log(ltompc_handle h, int* kind, int* width, double* ms, int capacity) {
+  if (!h) return fail("null handle");
+  const int n = (int)h->log_kind.size();
+  for (int i = 0; i < n && i < capacity; i++) {
+    if (kind) kind[i] = h->log_kind[i];
+    if (width) width[i] = h->log_width[i];
+    if (ms) ms[i] = h->log_ms[i];
+  }
+  return n;
 }
 
 int ltompc_get_history(ltompc_handle h, int* triples, int capacity) {

@@ -110,9 +110,17 @@ class BatchedMPC:
         ms, ln = np.zeros(7), np.zeros(7, dtype=np.int32)
         launches, its = C.c_int(), C.c_int()
         check(lib().ltompc_get_timing(self._h, dptr(ms), iptr(ln), C.byref(launches), C.byref(its)))
-        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "tail")
+        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1")
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
+
+    def launch_log(self):
+        """(kind, width, ms) arrays of every kernel launch of the profiled make_steps (set_profiling(True))."""
+        L = lib()
+        n = L.ltompc_get_launch_log(self._h, None, None, None, 0)
+        kind, width, ms = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(n)
+        L.ltompc_get_launch_log(self._h, iptr(kind), iptr(width), dptr(ms), n)
+        return kind, width, ms
 
     def history(self):
         buf = np.zeros((4096, 3), dtype=np.int32)

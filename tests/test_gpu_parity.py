@@ -229,10 +229,10 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     solved = s_ref["status"] == 0   # (iteration counts of unsolved instances depend on how many launches they were given)
     assert np.array_equal(s_nc["iters"][solved], s_ref["iters"][solved])
     monkeypatch.setenv("LTOMPC_COMPACT", "1")
-    monkeypatch.setenv("LTOMPC_TAIL", "0")   # wide launches only vs the one-wavefront-per-straggler kernel: same bits
+    monkeypatch.setenv("LTOMPC_RIC1", "0")   # 8-instances-per-wavefront sweep only vs one wavefront per instance in narrow launches: same bits
     u_nt, s_nt = run()
     assert np.array_equal(u_nt, u_ref) and np.array_equal(s_nt["iters"][solved], s_ref["iters"][solved])
-    monkeypatch.delenv("LTOMPC_TAIL")
+    monkeypatch.delenv("LTOMPC_RIC1")
     monkeypatch.delenv("LTOMPC_COMPACT")
     monkeypatch.setenv("LTOMPC_RICCATI", "serial")
     u_se, s_se = run()
