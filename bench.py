@@ -186,13 +186,14 @@ def main():
         u1 = m1.make_step(x1)
         x1 = m1.plant_step(x1, u1)
         torch.cuda.synchronize(dev)
-        tb = time.perf_counter()
-        nb = 5
-        for _ in range(nb):
+        nb, t_solve = 10, 0.0
+        for _ in range(nb):  # closed loop; only the solves are timed (host x0 in, host u0 out: PCIe included)
+            tb = time.perf_counter()
             u1 = m1.make_step(x1)
+            t_solve += time.perf_counter() - tb
             x1 = m1.plant_step(x1, u1)
-        torch.cuda.synchronize(dev)
-        extras["batch1_solves_per_s"] = nb / (time.perf_counter() - tb)
+        extras["batch1_solves_per_s"] = nb / t_solve
+        extras["batch1_ms_per_solve"] = 1e3 * t_solve / nb
         extras["batch1_iters_last"] = int(m1.iters[0])
         m1.close()
 

@@ -1683,7 +1683,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   }
 }
 
-__global__ void __launch_bounds__(64) k_linesearch(Consts K, Work W, int phase, int jw) {
+__global__ void __launch_bounds__(64, 2) k_linesearch(Consts K, Work W, int phase, int jw) {
   // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
   // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
   //          list of rejected instances; jw = launch width in instances, longer lists are covered grid-stride.

@@ -51,7 +51,10 @@ struct ltompc_solver {
   bool profiling = false;
   bool compaction = true;       // LTOMPC_COMPACT=0 switches the re-packing of unfinished instances off
   bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
-  std::vector<hipEvent_t> ev;  // pairs
+  // profiling: ONE event before every launch (and one closing a run of launches before the host waits); a launch's
+  // duration is the time to the next event.  Events come from a pool that lives as long as the handle.
+  std::vector<hipEvent_t> ev, ev_pool;
+  size_t ev_pool_used = 0;
   std::vector<int> ev_kind, ev_width;
   std::vector<int> log_kind, log_width;  // per launch of the profiled make_steps since profiling was switched on
   std::vector<double> log_ms;
@@ -93,36 +96,41 @@ struct Launcher {
   ltompc_solver* h;
   int launches = 0;
   size_t lds = 0;  // dynamic LDS bytes of the next launch (reset after it)
+  int stamp(int kind) {  // kind < 0: closes the preceding launch without opening one
+    if (h->ev_pool_used == h->ev_pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return fail("hipEventCreate failed");
+      h->ev_pool.push_back(e);
+    }
+    hipEvent_t e = h->ev_pool[h->ev_pool_used++];
+    if (hipEventRecord(e, h->stream) != hipSuccess) return fail("hipEventRecord failed");
+    h->ev.push_back(e), h->ev_kind.push_back(kind), h->ev_width.push_back(h->cur_width);
+    return 0;
+  }
+  int close() { return (h->profiling && !h->ev_kind.empty() && h->ev_kind.back() >= 0) ? stamp(-1) : 0; }
   template <typename Kern, typename... Args>
   int run(int kind, Kern kern, int threads_total, Args... args) {
     dim3 block(64), grid((threads_total + 63) / 64);
     const size_t lds_bytes = lds;
     lds = 0;
-    if (h->profiling) {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail("hipEventCreate failed");
-      hipEventRecord(a, h->stream);
-      hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
-      hipEventRecord(b, h->stream);
-      h->ev.push_back(a), h->ev.push_back(b), h->ev_kind.push_back(kind), h->ev_width.push_back(h->cur_width);
-    } else {
-      hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
-    }
+    if (h->profiling && stamp(kind)) return -1;
+    hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
     launches++;
     return 0;
   }
 };
 
 int collect_profile(ltompc_solver* h) {
-  for (size_t i = 0; i < h->ev_kind.size(); i++) {
+  for (size_t i = 0; i + 1 < h->ev_kind.size(); i++) {
+    if (h->ev_kind[i] < 0) continue;
     float ms = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+    HIPCHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     h->ms_by_kernel[h->ev_kind[i]] += ms;
     h->launches_by_kernel[h->ev_kind[i]] += 1;
     h->log_kind.push_back(h->ev_kind[i]), h->log_width.push_back(h->ev_width[i]), h->log_ms.push_back(ms);
-    hipEventDestroy(h->ev[2 * i]), hipEventDestroy(h->ev[2 * i + 1]);
   }
   h->ev.clear(), h->ev_kind.clear(), h->ev_width.clear();
+  h->ev_pool_used = 0;
   return 0;
 }
 
@@ -266,6 +274,7 @@ int ltompc_destroy(ltompc_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   for (void* p : h->allocs) hipFree(p);
+  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
   if (h->h_active) hipHostFree(h->h_active);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
@@ -370,6 +379,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     }
     if (L.run(5, k_update, N * np, h->K, W)) return -1;
     if ((it + 1) % h->poll_every == 0) {
+      if (L.close()) return -1;
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
@@ -385,6 +395,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       }
     }
   }
+  if (L.close()) return -1;
   hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev);
   HIPCHECK(hipGetLastError());
   h->last_launches = L.launches + 3;
