@@ -238,3 +238,89 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     u_se, s_se = run()
     ok = (s_se["status"] == 0) & (s_ref["status"] == 0)
     assert ok.mean() > 0.9 and np.abs(u_se - u_ref)[ok].max() < 1e-6
+
+
+def _midtrack_x0(tables, s):
+    """Noise-free state on the centre of the drivable band at arc length s."""
+    nl, nr = np.interp(s, tables.s_arc, tables.n_left), np.interp(s, tables.s_arc, tables.n_right)
+    vref, kap = np.interp(s, tables.s_arc, tables.v_ref), np.interp(s, tables.s_kappa, tables.kappa)
+    vx = 0.6 * vref
+    return np.array([[s, 0.5 * (nl - nr), 0.0, vx, 0.0, kap * vx, np.arctan(3.0 * kap), 0.1]])
+
+
+def test_config_c2_narrowest_band_cold_and_ten_warm_ticks(pkg, tables, oracle, gpu_lib):
+    """single instance at s = 416.26 m (narrowest feasible band), N = 40, cold start and 10 warm
+    ticks through the plant, against the same loop on the oracle."""
+    x = _midtrack_x0(tables, 416.26)
+    mpc = pkg.BatchedMPC(tables, 40, 1)
+    mpc.set_initial_guess(x)
+    ref, uprev = None, np.zeros((1, 2))
+    for tick in range(11):
+        u0 = mpc.make_step(x)
+        ref = oracle.solve(x, 40, uprev=uprev, warm=ref, prev_status=None if ref is None else ref["status"])
+        assert mpc.status[0] == 0 and ref["status"][0] == 0, tick
+        assert np.abs(u0 - ref["u0"]).max() < 1e-6, (tick, u0, ref["u0"])  # KKT tolerance 1e-8 on both sides
+        assert abs(int(mpc.iters[0]) - int(ref["iters"][0])) <= 2, tick
+        xn = mpc.plant_step(x, ref["u0"])
+        assert np.abs(xn - oracle.plant_step(x, ref["u0"])).max() < 1e-9
+        x, uprev = xn, ref["u0"]
+    mpc.close()
+
+
+def test_config_c3_batch_1024(pkg, tables, oracle, gpu_lib):
+    """B = 1024 sampled states, N = 40, cold start then 5 warm ticks through the plant.  The oracle
+    follows a 128-instance subset of the same batch (instances are independent: same numbers as in the full batch)."""
+    B, N, sub = 1024, 40, slice(0, 1024, 8)
+    x = pkg.sample_x0(tables, B)
+    opts = pkg.default_options(); opts.max_iter = 300
+    oo = oracle.o.max_iter
+    oracle.o.max_iter = 300
+    mpc = pkg.BatchedMPC(tables, N, B, options=opts)
+    mpc.set_initial_guess(x)
+    ref, uprev = None, np.zeros((B, 2))
+    try:
+        for tick in range(6):
+            u0 = mpc.make_step(x)
+            st = mpc.stats()
+            ref = oracle.solve(x[sub], N, uprev=uprev[sub], warm=ref, nthreads=16, prev_status=None if ref is None else ref["status"])
+            both = (st["status"][sub] == 0) & (ref["status"] == 0)
+            assert both.mean() > 0.9, (tick, both.mean())
+            assert (st["status"][sub] == ref["status"]).mean() > 0.97, tick
+            assert np.abs(u0[sub] - ref["u0"])[both].max() < 1e-5, tick
+            assert (np.abs(st["iters"][sub] - ref["iters"])[both] <= 2).mean() > 0.9, tick
+            assert (st["status"] == 0).mean() > (0.93 if tick == 0 else 0.97), (tick, np.bincount(st["status"], minlength=5))
+            # both sides continue from the GPU's controls (the subset's are equal to the oracle's to 1e-5 where solved,
+            # and the oracle warm-starts from its own previous iterate)
+            x, uprev = mpc.plant_step(x, u0), u0
+    finally:
+        oracle.o.max_iter = oo
+        mpc.close()
+
+
+def test_config_c5_closed_loop_n60(pkg, tables, oracle, gpu_lib):
+    """SURVEY.md §8d C5 (first 25 ticks): closed loop from the reference's x0 with horizon N = 60; the whole horizon of
+    an instance still fits the LDS staging of k_riccati1 (116 kB)."""
+    x = pkg.X0_REFERENCE[None].copy()
+    mpc = pkg.BatchedMPC(tables, 60, 1)
+    mpc.set_initial_guess(x)
+    ref, uprev = None, np.zeros((1, 2))
+    for tick in range(25):
+        u0 = mpc.make_step(x)
+        ref = oracle.solve(x, 60, uprev=uprev, warm=ref, prev_status=None if ref is None else ref["status"])
+        assert mpc.status[0] == 0 and ref["status"][0] == 0, tick
+        assert np.abs(u0 - ref["u0"]).max() < 1e-6, tick
+        x, uprev = mpc.plant_step(x, ref["u0"]), ref["u0"]
+    assert x[0, 0] > 10.0 and x[0, 3] > 5.0  # the car moved along the track and accelerated
+    mpc.close()
+
+
+def test_long_horizon_without_lds_staging(pkg, tables, oracle, gpu_lib):
+    """N = 80: an instance's horizon no longer fits the LDS staging (154 kB), narrow launches fall back to k_riccati8."""
+    x = np.stack([pkg.X0_REFERENCE, _midtrack_x0(tables, 300.0)[0]])
+    mpc = pkg.BatchedMPC(tables, 80, 2)
+    mpc.set_initial_guess(x)
+    u0 = mpc.make_step(x)
+    ref = oracle.solve(x, 80, nthreads=2)
+    assert (mpc.status == 0).all() and (ref["status"] == 0).all()
+    assert np.abs(u0 - ref["u0"]).max() < 1e-6
+    mpc.close()
