@@ -93,6 +93,11 @@ typedef struct ltompc_options {
                              restarts the equality multipliers at 0 and the barrier at mu_init (IPOPT's default
                              warm_start_init_point=no never re-uses multipliers; ours are re-used after a converged
                              solve only, the ones of a failed solve are what diverged) | 0: always re-use       (1) */
+  int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
+                             (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
+                             (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),
+                             0 = 1 for batches of at most 64 instances, else 2.  The two agree to ~1e-12 per iteration;
+                             bit-identical results across batches hold between handles of the same mode.     (0) */
 } ltompc_options;
 
 typedef struct ltompc_solver* ltompc_handle;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "eval8.h"
 
 using namespace ltompc;
 
@@ -61,6 +62,7 @@ struct ltompc_solver {
   int cur_width = 0;  // instances in the launches being issued
   double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
   int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
+  bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
@@ -216,6 +218,9 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->serial_riccati = e && std::string(e) == "serial";
     const char* c = getenv("LTOMPC_COMPACT");
     h->compaction = !(c && std::string(c) == "0");
+    const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
+    h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
+    if (ev) h->eval8 = std::string(ev) == "wave";
     const char* t = getenv("LTOMPC_RIC1");
     if (t) h->ric1_width = atoi(t);
     // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
@@ -356,7 +361,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   int it = 0;
   for (;; it++) {
     const int np = W.n_pad;
-    if (L.run(0, k_eval, N * np, h->K, W)) return -1;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->K, W) : L.run(0, k_eval, N * np, h->K, W)) return -1;
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->K, W, it)) return -1;
     } else {
@@ -369,7 +374,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       } else if (L.run(1, k_riccati8, np * 8, h->K, W, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (L.run(2, k_expand, N * np, h->K, W)) return -1;
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->K, W) : L.run(2, k_expand, N * np, h->K, W)) return -1;
     if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
     if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
     if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected

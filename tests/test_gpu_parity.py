@@ -324,3 +324,33 @@ def test_long_horizon_without_lds_staging(pkg, tables, oracle, gpu_lib):
     assert (mpc.status == 0).all() and (ref["status"] == 0).all()
     assert np.abs(u0 - ref["u0"]).max() < 1e-6
     mpc.close()
+
+
+def test_latency_mode_kernels_agree(pkg, tables, oracle, gpu_lib):
+    """options.latency_mode: the 8-lanes-per-slot evaluation kernels (k_eval8 / k_expand8, default for batches <= 64)
+    against the thread-per-slot ones: stage QP blocks equal to 1e-10 after one iteration, same iteration counts and
+    controls (1e-8) at convergence, and both equal to the oracle."""
+    B, N = 24, 20
+    x0 = pkg.sample_x0(tables, B, seed=5)
+    def run(mode, max_iter):
+        o = pkg.default_options(); o.latency_mode, o.max_iter = mode, max_iter
+        m = pkg.BatchedMPC(tables, N, B, options=o)
+        m.set_initial_guess(x0)
+        u = m.make_step(x0)
+        out = dict(u0=u, qp=m.debug_fetch(0).copy(), dc=m.debug_fetch(7).copy(), nl2=m.debug_fetch(11).copy(),
+                   iters=m.iters.copy(), status=m.status.copy())
+        m.close()
+        return out
+    a, b = run(2, 1), run(1, 1)
+    for key in ("qp", "dc", "nl2"):
+        scale = np.maximum(np.maximum(np.abs(a[key]), np.abs(b[key])), 1e-3)
+        assert (np.abs(a[key] - b[key]) / scale).max() < 1e-10, key
+    a, b, auto = run(2, 300), run(1, 300), run(0, 300)
+    assert np.array_equal(auto["u0"], b["u0"])  # 24 instances: auto = latency mode
+    ok = (a["status"] == 0) & (b["status"] == 0)
+    assert ok.mean() > 0.9 and np.array_equal(a["status"], b["status"])
+    assert np.abs(a["u0"] - b["u0"])[ok].max() < 1e-8
+    assert (np.abs(a["iters"] - b["iters"])[ok] <= 1).all()
+    ref = oracle.solve(x0, N, nthreads=8)
+    both = ok & (ref["status"] == 0)
+    assert np.abs(b["u0"] - ref["u0"])[both].max() < 1e-6
