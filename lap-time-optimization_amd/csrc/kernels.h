@@ -51,7 +51,9 @@ enum : int { SP_apri = 0, SP_adua, SP_gphid, SP_NF };
 // per-instance double state
 enum : int {
   ST_MU = 0, ST_EPS, ST_EPS_NEXT, ST_DW_LAST, ST_FORCE_REG, ST_ALPHA, ST_ADUA, ST_E0, ST_OBJ, ST_TAU,
-  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY, ST_NF
+  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY,
+  ST_C00,  // lterm(x_0) for the current ST_EPS: a constant of the solve between two changes of the table smoothing
+  ST_NF
 };
 // per-instance int state
 // SI_LSMORE: the full step was rejected by the filter test, the remaining step candidates have to be evaluated.
@@ -387,6 +389,7 @@ __global__ void k_init(Consts K, Work W, int cold) {
     st[(size_t)ST_E0 * W.Bp + b] = 1e300, st[(size_t)ST_OBJ * W.Bp + b] = 0.0, st[(size_t)ST_TAU * W.Bp + b] = 0.99;
     st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
     st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
+    st[(size_t)ST_C00 * W.Bp + b] = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
     for (int i = 0; i < SI_NF; i++)
       if (i != SI_PREV) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
@@ -541,12 +544,7 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
   // ---- reduce residual partials, KKT error, termination (IPOPT eq. (5),(6)) ----
   double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, smult = 0.0;
   double obj;
-  {
-    double x0[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
-    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);  // lterm(x_0), constant
-  }
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) {
     rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
     cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
@@ -898,13 +896,7 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   }
   rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
   double smult = 0.0, obj;
-  {
-    double x0[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) x0[j] = W.x0[(size_t)j * W.Bp + b];
-    if (!live) x0[3] = 1.0;  // keep atan(vy/vx) finite on padding lanes
-    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
-  }
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
   const int n_mult = N * (2 * NX + K.bd.ni) - 3;
   double mu = STD(ST_MU);
@@ -1219,13 +1211,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   }
   rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
   double smult = 0.0, obj;
-  {
-    double x0[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) x0[j] = W.x0[(size_t)j * W.Bp + b];
-    if (!live) x0[3] = 1.0;  // keep atan(vy/vx) finite on padding lanes
-    obj = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
-  }
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
   const int n_mult = N * (2 * NX + K.bd.ni) - 3;
   double mu = STD(ST_MU);
@@ -1718,13 +1704,7 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   }
   a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
   // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
-  double c00;
-  {
-    double x0[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) x0[q] = W.x0[(size_t)q * W.Bp + b];
-    c00 = cost_eval(K.p, K.T, STD(ST_EPS), x0, false, nullptr, nullptr);
-  }
+  const double c00 = STD(ST_C00);
   auto measures = [&](int l, double& th, double& ph) {
     double t = 0.0, c = 0.0, s = 0.0;
     for (int k = i; k < N; k += 8) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
@@ -1823,6 +1803,12 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   bool eps_switched = false;
   if (STD(ST_EPS_NEXT) != STD(ST_EPS)) {
     STD(ST_EPS) = STD(ST_EPS_NEXT);
+    {
+      double x0[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) x0[q] = W.x0[(size_t)q * W.Bp + b];
+      STD(ST_C00) = cost_eval(K.p, K.T, STD(ST_EPS_NEXT), x0, false, nullptr, nullptr);
+    }
     nfilt = 0, STD(ST_THETA0) = -1.0;
     eps_switched = true;
   }
@@ -1869,6 +1855,29 @@ __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
   d_update(K, W, k, W.act[j]);
 }
 
+
+// ------------------------------------------------------------------------------------------ k_step1
+// Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
+// and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
+__global__ void __launch_bounds__(320) k_step1(Consts K, Work W) {  // 320 = 7 candidates x 40 intervals in one pass
+  if ((int)blockIdx.x >= W.nact[0]) return;
+  const int b = W.act[blockIdx.x];
+  const int N = W.N, tid = threadIdx.x;
+  const int* si = W.si;
+  if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
+  for (int kk = tid; kk < N; kk += 320) d_linesearch(K, W, kk, b, 1, 1);
+  __syncthreads();
+  if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
+  __syncthreads();
+  if (si[(size_t)SI_LSMORE * W.Bp + b]) {  // block-uniform (written before the barrier)
+    const int nc = K.o.n_linesearch - 1;
+    for (int idx = tid; idx < N * nc; idx += 320) d_linesearch(K, W, idx % N, b, 2 + idx / N, 2 + idx / N);
+    __syncthreads();
+    if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
+    __syncthreads();
+  }
+  for (int kk = tid; kk < N; kk += 320) d_update(K, W, kk, b);
+}
 
 // ------------------------------------------------------------------------------------------ compaction
 __global__ void k_act_identity(int* act, int* nact, int B) {

@@ -63,6 +63,7 @@ struct ltompc_solver {
   double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
   int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
+  int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
@@ -98,6 +99,7 @@ struct Launcher {
   ltompc_solver* h;
   int launches = 0;
   size_t lds = 0;  // dynamic LDS bytes of the next launch (reset after it)
+  int block_threads = 64;  // workgroup size of the next launch (reset after it)
   int stamp(int kind) {  // kind < 0: closes the preceding launch without opening one
     if (h->ev_pool_used == h->ev_pool.size()) {
       hipEvent_t e;
@@ -112,9 +114,9 @@ struct Launcher {
   int close() { return (h->profiling && !h->ev_kind.empty() && h->ev_kind.back() >= 0) ? stamp(-1) : 0; }
   template <typename Kern, typename... Args>
   int run(int kind, Kern kern, int threads_total, Args... args) {
-    dim3 block(64), grid((threads_total + 63) / 64);
+    dim3 block(block_threads), grid((threads_total + block_threads - 1) / block_threads);
     const size_t lds_bytes = lds;
-    lds = 0;
+    lds = 0, block_threads = 64;
     if (h->profiling && stamp(kind)) return -1;
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
     launches++;
@@ -221,6 +223,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
     h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
     if (ev) h->eval8 = std::string(ev) == "wave";
+    const char* s1 = getenv("LTOMPC_STEP1");
+    if (s1) h->step1_width = atoi(s1);
     const char* t = getenv("LTOMPC_RIC1");
     if (t) h->ric1_width = atoi(t);
     // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
@@ -375,14 +379,20 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
     if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->K, W) : L.run(2, k_expand, N * np, h->K, W)) return -1;
-    if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
-    if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
-    if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
-      const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
-      if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->K, W, 1, jw)) return -1;
-      if (L.run(4, k_pick, np * 8, h->K, W, 1)) return -1;
+    if (n_launch <= h->step1_width) {
+      // one workgroup per instance does both line-search phases, the filter test and the update
+      L.block_threads = 320;
+      if (L.run(3, k_step1, n_launch * 320, h->K, W)) return -1;
+    } else {
+      if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
+      if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
+      if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
+        const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
+        if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->K, W, 1, jw)) return -1;
+        if (L.run(4, k_pick, np * 8, h->K, W, 1)) return -1;
+      }
+      if (L.run(5, k_update, N * np, h->K, W)) return -1;
     }
-    if (L.run(5, k_update, N * np, h->K, W)) return -1;
     if ((it + 1) % h->poll_every == 0) {
       if (L.close()) return -1;
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));

@@ -1,0 +1,26 @@
+"""Per kernel class and launch width: number of launches and average device time, for one warm tick at B = 8192."""
+import sys, os, time, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import ltompc
+T = ltompc.build_tables()
+B, N = 8192, 40
+x0 = ltompc.sample_x0(T, B)
+o = ltompc.default_options(); o.max_iter = 150
+m = ltompc.BatchedMPC(T, N, B, options=o); m.set_initial_guess(x0)
+u0 = m.make_step(x0)
+for tick in range(3):
+    x0 = m.plant_step(x0, u0)
+    m.set_profiling(tick == 2)
+    t0 = time.perf_counter(); u0 = m.make_step(x0); dt = time.perf_counter() - t0
+kind, width, ms = m.launch_log()
+names = ["eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1"]
+print(f"tick {dt*1e3:.1f} ms, sum of kernel time {ms.sum():.1f} ms, launches {len(ms)}")
+bins = [(8192, 8192), (2049, 8191), (513, 2048), (65, 512), (9, 64), (1, 8)]
+print("kernel       " + "".join(f"{f'{lo}..{hi}':>22s}" for hi, lo in [(b[1], b[0]) for b in bins]))
+for q, nm in enumerate(names):
+    row = f"{nm:12s} "
+    for lo, hi in bins:
+        sel = (kind == q) & (width >= lo) & (width <= hi)
+        row += f"{int(sel.sum()):5d} x {ms[sel].mean()*1e3 if sel.any() else 0:7.1f}us ={ms[sel].sum():6.1f}"
+    print(row)
+tot = [ms[(width >= lo) & (width <= hi)].sum() for lo, hi in bins]
+print("total ms     " + "".join(f"{t:22.1f}" for t in tot))

@@ -5,7 +5,7 @@ T = ltompc.build_tables()
 B, N, MI = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 x0 = ltompc.sample_x0(T, max(B, 2))[:B]
 def run(tail):
-    os.environ["LTOMPC_RIC1"] = str(tail)
+    os.environ["LTOMPC_RIC1"] = str(tail); os.environ["LTOMPC_STEP1"] = str(tail)
     o = ltompc.default_options(); o.max_iter = MI
     m = ltompc.BatchedMPC(T, N, B, options=o)
     m.set_initial_guess(x0); u0 = m.make_step(x0)

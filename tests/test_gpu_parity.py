@@ -230,9 +230,11 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     assert np.array_equal(s_nc["iters"][solved], s_ref["iters"][solved])
     monkeypatch.setenv("LTOMPC_COMPACT", "1")
     monkeypatch.setenv("LTOMPC_RIC1", "0")   # 8-instances-per-wavefront sweep only vs one wavefront per instance in narrow launches: same bits
+    monkeypatch.setenv("LTOMPC_STEP1", "0")  # separate line-search / pick / update launches vs the fused step-selection kernel: same bits
     u_nt, s_nt = run()
     assert np.array_equal(u_nt, u_ref) and np.array_equal(s_nt["iters"][solved], s_ref["iters"][solved])
     monkeypatch.delenv("LTOMPC_RIC1")
+    monkeypatch.delenv("LTOMPC_STEP1")
     monkeypatch.delenv("LTOMPC_COMPACT")
     monkeypatch.setenv("LTOMPC_RICCATI", "serial")
     u_se, s_se = run()
