@@ -31,6 +31,7 @@ BYTES_BY_KERNEL = {  # share of the 3104 B each kernel class moves (algorithmic,
     "eval": 8 * (WORDS_QP + WORDS_EVAL_IN), "riccati": 8 * (WORDS_QP + WORDS_RIC_OUT),
     "expand": 8 * (WORDS_EVAL_IN + WORDS_RIC_OUT), "linesearch": 8 * WORDS_EVAL_IN, "pick": 0, "update": 8 * 2 * WORDS_EVAL_IN,
     "riccati1": 0,  # one-wavefront-per-instance sweep of the narrow launches: latency-bound by construction, no roofline claim
+    "step1": 0,     # fused line-search / pick / update kernel of the narrow launches: likewise
 }
 
 
@@ -247,6 +248,13 @@ def main():
                          f"({nthreads} threads of {ncores} host cores), {tcpu:.1f}s wall; oracle/ltompc_oracle.c "
                          "(do_mpc/IPOPT itself is not installable offline)",
                "iters_mean": float(r2["iters"].mean()), "solved_frac": float((r2["status"] == 0).mean())}
+        # the reference's own mode of operation is one process, one instance at a time: same oracle, one thread
+        S1 = min(64, S)
+        w1 = {k: r[k][:S1] for k in ("X", "C", "U", "L1", "L2")}
+        tc = time.perf_counter()
+        O.solve(xs1[:S1], N, uprev=r["u0"][:S1], warm=w1, nthreads=1)
+        cpu["single_thread_value"] = S1 / (time.perf_counter() - tc)
+        cpu["single_thread_sample"] = f"first {S1} instances of the same tick, 1 thread"
 
     if rank == 0:
         out = {

@@ -172,12 +172,12 @@ int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:
- * index 0 eval, 1 riccati (8 instances per wavefront), 2 expand, 3 linesearch, 4 pick, 5 update, 6 riccati1 (the
- * one-wavefront-per-instance sweep used once few instances are left).  launches / ip_iterations (iterations launched)
- * refer to the last make_step.
- * Arrays have 7 entries.  Any output may be NULL. */
+ * index 0 eval (k_eval or k_eval8), 1 riccati (8 instances per wavefront), 2 expand (k_expand or k_expand8), 3 linesearch,
+ * 4 pick, 5 update, 6 riccati1 (the one-wavefront-per-instance sweep of the narrow launches), 7 step1 (their fused
+ * line-search / pick / update kernel).  launches / ip_iterations (iterations launched) refer to the last make_step.
+ * Arrays have 8 entries.  Any output may be NULL. */
 int ltompc_set_profiling(ltompc_handle h, int on);
-int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_kernel7, int* launches,
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel8, int* launches_by_kernel8, int* launches,
                       int* ip_iterations);
 /* Per-launch log of the profiled make_steps since profiling was switched on: kernel class (index as above), launch
  * width (instances the launch was sized for: the whole batch until the first re-packing of the unfinished instances)

@@ -99,13 +99,14 @@ struct Consts {
 #define PG(base, f, k, NF) ((base)[(((size_t)(k) * (W.Bp >> 3) + (b >> 3)) * (NF) + (f)) * 8 + (b & 7)])
 
 // ------------------------------------------------------------------------------------------ small dense LA
-__device__ __forceinline__ bool lu8(double* M) {  // in place, no pivoting (M = 4.5 I + 2 E2 E1)
+__device__ __forceinline__ bool lu8(double* M) {  // in place, no pivoting (M = 4.5 I + 2 E2 E1); diagonal: 1 / pivot
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     double pv = M[k * 8 + k];
     ok = ok && (fabs(pv) > 1e-12);
     double ip = 1.0 / pv;
+    M[k * 8 + k] = ip;  // the solves multiply by the reciprocal pivot (8 divisions per factorisation instead of 8 per solve)
 #pragma unroll
     for (int i = k + 1; i < 8; i++) {
       double l = M[i * 8 + k] * ip;
@@ -125,7 +126,7 @@ __device__ __forceinline__ void lu8_solve(const double* M, double* v) {
   for (int i = 7; i >= 0; i--) {
 #pragma unroll
     for (int j = i + 1; j < 8; j++) v[i] -= M[i * 8 + j] * v[j];
-    v[i] /= M[i * 8 + i];
+    v[i] *= M[i * 8 + i];
   }
 }
 __device__ __forceinline__ void lu8_solve_t(const double* M, double* v) {  // M^T x = v
@@ -133,7 +134,7 @@ __device__ __forceinline__ void lu8_solve_t(const double* M, double* v) {  // M^
   for (int i = 0; i < 8; i++) {
 #pragma unroll
     for (int j = 0; j < i; j++) v[i] -= M[j * 8 + i] * v[j];
-    v[i] /= M[i * 8 + i];
+    v[i] *= M[i * 8 + i];
   }
 #pragma unroll
   for (int i = 7; i >= 0; i--)

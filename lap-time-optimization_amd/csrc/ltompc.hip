@@ -29,7 +29,7 @@ int fail(const std::string& msg) {
     if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));      \
   } while (0)
 
-constexpr int NKERN = 7;  // eval, riccati, expand, linesearch, pick, update, riccati1
+constexpr int NKERN = 8;  // eval, riccati, expand, linesearch, pick, update, riccati1, step1
 
 }  // namespace
 
@@ -60,8 +60,8 @@ struct ltompc_solver {
   std::vector<int> log_kind, log_width;  // per launch of the profiled make_steps since profiling was switched on
   std::vector<double> log_ms;
   int cur_width = 0;  // instances in the launches being issued
-  double ms_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
-  int launches_by_kernel[NKERN] = {0, 0, 0, 0, 0, 0, 0};
+  double ms_by_kernel[NKERN] = {};
+  int launches_by_kernel[NKERN] = {};
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
@@ -382,7 +382,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     if (n_launch <= h->step1_width) {
       // one workgroup per instance does both line-search phases, the filter test and the update
       L.block_threads = 320;
-      if (L.run(3, k_step1, n_launch * 320, h->K, W)) return -1;
+      if (L.run(7, k_step1, n_launch * 320, h->K, W)) return -1;
     } else {
       if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
       if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
@@ -528,11 +528,11 @@ int ltompc_slip_forces(ltompc_handle h, const double* x, int batch, double* alph
   return 0;
 }
 
-int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel7, int* launches_by_kernel7, int* launches, int* ip_iterations) {
+int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel8, int* launches_by_kernel8, int* launches, int* ip_iterations) {
   if (!h) return fail("null handle");
   for (int i = 0; i < NKERN; i++) {
-    if (ms_by_kernel7) ms_by_kernel7[i] = h->ms_by_kernel[i];
-    if (launches_by_kernel7) launches_by_kernel7[i] = h->launches_by_kernel[i];
+    if (ms_by_kernel8) ms_by_kernel8[i] = h->ms_by_kernel[i];
+    if (launches_by_kernel8) launches_by_kernel8[i] = h->launches_by_kernel[i];
   }
   if (launches) *launches = h->last_launches;
   if (ip_iterations) *ip_iterations = h->last_iterations;

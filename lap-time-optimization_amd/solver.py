@@ -107,10 +107,10 @@ class BatchedMPC:
         check(lib().ltompc_set_poll_every(self._h, int(n)))
 
     def timing(self):
-        ms, ln = np.zeros(7), np.zeros(7, dtype=np.int32)
+        ms, ln = np.zeros(8), np.zeros(8, dtype=np.int32)
         launches, its = C.c_int(), C.c_int()
         check(lib().ltompc_get_timing(self._h, dptr(ms), iptr(ln), C.byref(launches), C.byref(its)))
-        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1")
+        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1")
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
 

@@ -12,7 +12,7 @@ for tick in range(3):
     m.set_profiling(tick == 2)
     t0 = time.perf_counter(); u0 = m.make_step(x0); dt = time.perf_counter() - t0
 kind, width, ms = m.launch_log()
-names = ["eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1"]
+names = ["eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1"]
 print(f"tick {dt*1e3:.1f} ms, sum of kernel time {ms.sum():.1f} ms, launches {len(ms)}")
 bins = [(8192, 8192), (2049, 8191), (513, 2048), (65, 512), (9, 64), (1, 8)]
 print("kernel       " + "".join(f"{f'{lo}..{hi}':>22s}" for hi, lo in [(b[1], b[0]) for b in bins]))
