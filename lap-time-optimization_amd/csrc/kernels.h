@@ -283,52 +283,147 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
 
 // Elimination of the collocation point: with M8 = 4.5 I + 2 E2 E1,
 //   M8 dc = (2I - 4E2) dx - (I + 2E2) Bu du - G2 - 2 E2 G1 ,   dx+ = 2 (E1 dc + 2 dx + Bu du + G1)
-// Y = [Ac | Bc | bc] (8 x 11), AB = [A | B | b] (8 x 11); M8 holds its LU factors on return.
-__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, double* M8, double* Y, double* AB) {
+// Y = [Ac | Bc | bc] (8 x 11), AB = [A | B | b] (8 x 11).
+//
+// Structure.  With the states grouped a = (s, n, mu), b = (vx, vy, r), c = (delta, T): the kinematic rows of the
+// model do not depend on c, the dynamic rows do not depend on a, and the rows of c are d/dt = u.  Hence E1, E2 are
+// block UPPER triangular in (a, b, c) with E_ac = 0 and E_cc = -1.5 I / -2.5 I, so are M8 (with M_cc = 12 I), the
+// first 8 columns of Y and A (with A_cc = I): the elimination is two 3x3 inverses and block back-substitutions, and
+// every product below runs over the structurally non-zero range only (less than half of the dense flops).
+__host__ __device__ constexpr int gs_(int i) { return i < 3 ? 0 : (i < 6 ? 3 : 6); }  // first index of i's group
+__host__ __device__ constexpr int ge_(int i) { return i < 3 ? 2 : (i < 6 ? 5 : 7); }  // last index of i's group
+// row i of E1 / E2 is non-zero in columns elo_(i) .. ehi_(i)
+__host__ __device__ constexpr int elo_(int i) { return i < 6 ? gs_(i) : i; }
+__host__ __device__ constexpr int ehi_(int i) { return i < 3 ? 5 : (i < 6 ? 7 : i); }
+// column col of Y = [Ac | Bc | bc] is non-zero in rows 0 .. yrow_(col)
+__host__ __device__ constexpr int yrow_(int col) { return col < 8 ? ge_(col) : 7; }
+__host__ __device__ constexpr int imin_(int x, int y) { return x < y ? x : y; }
+__host__ __device__ constexpr int imax_(int x, int y) { return x > y ? x : y; }
+
+struct M8Blocks {  // M8 = [[Maa Mab Mac], [0 Mbb Mbc], [0 0 12 I]]
+  double iaa[9], ibb[9];  // inverses of the diagonal blocks
+  double ab[9], ac[6], bc[6];
+};
+
+__device__ __forceinline__ bool inv33(const double* m, double* r) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const double id = 1.0 / det;
+  r[0] = c00 * id, r[1] = (m[2] * m[7] - m[1] * m[8]) * id, r[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  r[3] = c01 * id, r[4] = (m[0] * m[8] - m[2] * m[6]) * id, r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  r[6] = c02 * id, r[7] = (m[1] * m[6] - m[0] * m[7]) * id, r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  return fabs(det) > 1e-12;
+}
+
+// y = M8^-1 v for a right-hand side whose rows > RMAX are structurally zero (those of y are then zero too, not written)
+template <int RMAX>
+__device__ __forceinline__ void m8_solve(const M8Blocks& M, const double* v, double* y) {
+  double yc[2] = {0.0, 0.0}, yb[3] = {0.0, 0.0, 0.0};
+  if (RMAX >= 6) {
+    yc[0] = v[6] * (1.0 / 12.0), yc[1] = v[7] * (1.0 / 12.0);
+    y[6] = yc[0], y[7] = yc[1];
+  }
+  if (RMAX >= 3) {
+    double rb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      rb[i] = v[3 + i];
+      if (RMAX >= 6) rb[i] -= M.bc[i * 2] * yc[0] + M.bc[i * 2 + 1] * yc[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) yb[i] = M.ibb[i * 3] * rb[0] + M.ibb[i * 3 + 1] * rb[1] + M.ibb[i * 3 + 2] * rb[2], y[3 + i] = yb[i];
+  }
+  double ra[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    ra[i] = v[i];
+    if (RMAX >= 3) ra[i] -= M.ab[i * 3] * yb[0] + M.ab[i * 3 + 1] * yb[1] + M.ab[i * 3 + 2] * yb[2];
+    if (RMAX >= 6) ra[i] -= M.ac[i * 2] * yc[0] + M.ac[i * 2 + 1] * yc[1];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) y[i] = M.iaa[i * 3] * ra[0] + M.iaa[i * 3 + 1] * ra[1] + M.iaa[i * 3 + 2] * ra[2];
+}
+// x = M8^-T v (dense v): forward substitution through the transposed blocks
+__device__ __forceinline__ void m8_solve_t(const M8Blocks& M, const double* v, double* x) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) x[i] = M.iaa[i] * v[0] + M.iaa[3 + i] * v[1] + M.iaa[6 + i] * v[2];
+  double rb[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) rb[i] = v[3 + i] - (M.ab[i] * x[0] + M.ab[3 + i] * x[1] + M.ab[6 + i] * x[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) x[3 + i] = M.ibb[i] * rb[0] + M.ibb[3 + i] * rb[1] + M.ibb[6 + i] * rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double s = v[6 + i];
+#pragma unroll
+    for (int l = 0; l < 3; l++) s -= M.ac[l * 2 + i] * x[l] + M.bc[l * 2 + i] * x[3 + l];
+    x[6 + i] = s * (1.0 / 12.0);
+  }
+}
+
+template <int COL>
+__device__ __forceinline__ void condense_column(const Consts& K, const Slot& S, const M8Blocks& M, double* Y, double* AB) {
   const double hdt = K.o.t_step;
+  constexpr int RM = yrow_(COL);
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (COL < 8) {
 #pragma unroll
-  for (int i = 0; i < 8; i++)
+    for (int i = 0; i <= RM; i++) v[i] = ((i == COL) ? 2.0 : 0.0) - ((COL >= elo_(i) && COL <= ehi_(i)) ? 4.0 * S.E2[i * 8 + COL] : 0.0);
+  } else if (COL < 10) {
+    constexpr int j = 6 + COL - 8;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      double s = (i == j) ? 4.5 : 0.0;
-#pragma unroll
-      for (int l = 0; l < 8; l++) s += 2.0 * S.E2[i * 8 + l] * S.E1[l * 8 + j];
-      M8[i * 8 + j] = s;
-    }
-  bool ok = lu8(M8);
-#pragma unroll
-  for (int col = 0; col < 11; col++) {
-    double v[8];
-    if (col < 8) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = ((i == col) ? 2.0 : 0.0) - 4.0 * S.E2[i * 8 + col];
-    } else if (col < 10) {
-      int j = 6 + col - 8;
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = -hdt * (((i == j) ? 1.0 : 0.0) + 2.0 * S.E2[i * 8 + j]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        double s = -S.G2[i];
-#pragma unroll
-        for (int l = 0; l < 8; l++) s -= 2.0 * S.E2[i * 8 + l] * S.G1[l];
-        v[i] = s;
-      }
-    }
-    lu8_solve(M8, v);
-#pragma unroll
-    for (int i = 0; i < 8; i++) Y[i * 11 + col] = v[i];
+    for (int i = 0; i < 8; i++) v[i] = -hdt * (((i == j) ? 1.0 : 0.0) + ((j >= elo_(i) && j <= ehi_(i)) ? 2.0 * S.E2[i * 8 + j] : 0.0));
+  } else {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      double s;
-      if (col < 8) s = (i == col) ? 2.0 : 0.0;
-      else if (col < 10) s = (i == 6 + col - 8) ? hdt : 0.0;
-      else s = S.G1[i];
+      double s = -S.G2[i];
 #pragma unroll
-      for (int l = 0; l < 8; l++) s += S.E1[i * 8 + l] * v[l];
-      AB[i * 11 + col] = 2.0 * s;
+      for (int l = elo_(i); l <= ehi_(i); l++) s -= 2.0 * S.E2[i * 8 + l] * S.G1[l];
+      v[i] = s;
     }
   }
+  m8_solve<RM>(M, v, y);
+#pragma unroll
+  for (int i = 0; i <= RM; i++) Y[i * 11 + COL] = y[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s;
+    if (COL < 8) s = (i == COL) ? 2.0 : 0.0;
+    else if (COL < 10) s = (i == 6 + COL - 8) ? hdt : 0.0;
+    else s = S.G1[i];
+#pragma unroll
+    for (int l = elo_(i); l <= imin_(ehi_(i), RM); l++) s += S.E1[i * 8 + l] * y[l];
+    AB[i * 11 + COL] = 2.0 * s;
+  }
+}
+
+__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8Blocks& M, double* Y, double* AB) {
+  // M8(i, j) = 4.5 delta_ij + 2 sum_l E2(i, l) E1(l, j): l runs where row i of E2 and column j of E1 overlap
+  double maa[9], mbb[9];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = gs_(i); j < 8; j++) {
+      double s = (i == j) ? 4.5 : 0.0;
+#pragma unroll
+      for (int l = elo_(i); l <= imin_(ehi_(i), ge_(j)); l++)
+        if (j >= elo_(l) && j <= ehi_(l)) s += 2.0 * S.E2[i * 8 + l] * S.E1[l * 8 + j];
+      if (i < 3) {
+        if (j < 3) maa[i * 3 + j] = s;
+        else if (j < 6) M.ab[i * 3 + j - 3] = s;
+        else M.ac[i * 2 + j - 6] = s;
+      } else {
+        if (j < 6) mbb[(i - 3) * 3 + j - 3] = s;
+        else M.bc[(i - 3) * 2 + j - 6] = s;
+      }
+    }
+  const bool ok = inv33(maa, M.iaa) & inv33(mbb, M.ibb);
+#pragma unroll
+  for (int q = 0; q < 88; q++) Y[q] = 0.0, AB[q] = 0.0;
+  condense_column<0>(K, S, M, Y, AB), condense_column<1>(K, S, M, Y, AB), condense_column<2>(K, S, M, Y, AB);
+  condense_column<3>(K, S, M, Y, AB), condense_column<4>(K, S, M, Y, AB), condense_column<5>(K, S, M, Y, AB);
+  condense_column<6>(K, S, M, Y, AB), condense_column<7>(K, S, M, Y, AB), condense_column<8>(K, S, M, Y, AB);
+  condense_column<9>(K, S, M, Y, AB), condense_column<10>(K, S, M, Y, AB);
   return ok;
 }
 
@@ -450,7 +545,8 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
       double rcx = S.dcd[a] + 4.5 * l2[a];
       double rxp = S.dxd[a] - 0.5 * l1[a];
 #pragma unroll
-      for (int i = 0; i < 8; i++) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
+      for (int i = 0; i <= ge_(a); i++)  // column a of E1 / E2: rows of the groups up to a's
+        if (a >= elo_(i) && a <= ehi_(i)) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
       if (k + 1 < N) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);
       rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
       rp = fmax(rp, fmax(fabs(S.G1[a]), fabs(S.G2[a])));
@@ -477,7 +573,8 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
   }
   // ---- eliminate the collocation point, project its QP block onto (x_k, u_k) ----
-  double M8[64], Y[88], AB[88];
+  M8Blocks M8;
+  double Y[88], AB[88];
   condense_slot(K, S, M8, Y, AB);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -486,14 +583,14 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     PG(W.QP, QP_B + i * 2 + 0, k, QP_NF) = AB[i * 11 + 8], PG(W.QP, QP_B + i * 2 + 1, k, QP_NF) = AB[i * 11 + 9];
     PG(W.QP, QP_b + i, k, QP_NF) = AB[i * 11 + 10];
   }
-  double HY[88];  // Hc * [Ac | Bc | bc]
+  double HY[88];  // Hc * [Ac | Bc | bc]; column col of Y is non-zero in rows 0 .. yrow_(col)
 #pragma unroll
   for (int i = 0; i < 8; i++)
 #pragma unroll
     for (int col = 0; col < 11; col++) {
       double s = 0.0;
 #pragma unroll
-      for (int l = 0; l < 8; l++) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
+      for (int l = 0; l <= yrow_(col); l++) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
       HY[i * 11 + col] = s;
     }
   // Q = Ac^T Hc Ac, S = Bc^T Hc Ac, R = Bc^T Hc Bc + Du; q = [Ac|Bc]^T (Hc bc + gc0 + mu gc1) (+ gub)
@@ -504,14 +601,14 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
       if (j > i) continue;
       double s = 0.0;
 #pragma unroll
-      for (int l = 0; l < 8; l++) s += Y[l * 11 + i] * HY[l * 11 + j];
+      for (int l = 0; l <= yrow_(i); l++) s += Y[l * 11 + i] * HY[l * 11 + j];
       if (i < 8) PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) = s;
       else if (j < 8) PG(W.QP, QP_S + (i - 8) * 8 + j, k, QP_NF) = s;
       else PG(W.QP, QP_R + sidx(i - 8, j - 8), k, QP_NF) = s + ((i == j) ? S.Du[i - 8] : 0.0);
     }
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int l = 0; l < 8; l++) s0 += Y[l * 11 + i] * (HY[l * 11 + 10] + S.gc0[l]), s1 += Y[l * 11 + i] * S.gc1[l];
+    for (int l = 0; l <= yrow_(i); l++) s0 += Y[l * 11 + i] * (HY[l * 11 + 10] + S.gc0[l]), s1 += Y[l * 11 + i] * S.gc1[l];
     if (i < 8) PG(W.QP, QP_q0 + i, k, QP_NF) = s0, PG(W.QP, QP_q1 + i, k, QP_NF) = s1;
     else PG(W.QP, QP_r0 + i - 8, k, QP_NF) = s0 + S.gub0[i - 8], PG(W.QP, QP_r1 + i - 8, k, QP_NF) = s1 + S.gub1[i - 8];
   }
@@ -1510,7 +1607,8 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
   Slot S;
   linearise_slot<false>(K, W, k, b, eps, S);
-  double M8[64], Y[88], AB[88];
+  M8Blocks M8;
+  double Y[88], AB[88];
   condense_slot(K, S, M8, Y, AB);
   double dxk[8], dxp[8], du[2], dc[8];
 #pragma unroll
@@ -1520,7 +1618,8 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   for (int i = 0; i < 8; i++) {
     double s = Y[i * 11 + 10] + Y[i * 11 + 8] * du[0] + Y[i * 11 + 9] * du[1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += Y[i * 11 + j] * dxk[j];
+    for (int j = gs_(i); j < 8; j++)  // row i of Ac: block upper triangular, its (delta, T) block is the identity
+      if (i < 6 || j == i) s += Y[i * 11 + j] * dxk[j];
     dc[i] = s;
     PL(W.dC, i, k, N) = s;
   }
@@ -1540,15 +1639,24 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   for (int i = 0; i < 8; i++) {
     double s = S.gc0[i] + mu * S.gc1[i];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += sym_get(S.Hc, i, j) * dc[j] + 2.0 * S.E1[j * 8 + i] * pi[j];
+    for (int j = 0; j < 8; j++) {
+      s += sym_get(S.Hc, i, j) * dc[j];
+      if (i >= elo_(j) && i <= ehi_(j)) s += 2.0 * S.E1[j * 8 + i] * pi[j];
+    }
     v[i] = -s;
   }
-  lu8_solve_t(M8, v);
+  {
+    double l2[8];
+    m8_solve_t(M8, v, l2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = l2[i];
+  }
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     double s = pi[i];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += S.E2[j * 8 + i] * v[j];
+    for (int j = 0; j < 8; j++)
+      if (i >= elo_(j) && i <= ehi_(j)) s += S.E2[j * 8 + i] * v[j];
     PL(W.nL1, i, k, N) = 2.0 * s;
     PL(W.nL2, i, k, N) = v[i];
   }
