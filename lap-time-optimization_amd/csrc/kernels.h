@@ -297,6 +297,9 @@ __host__ __device__ constexpr int elo_(int i) { return i < 6 ? gs_(i) : i; }
 __host__ __device__ constexpr int ehi_(int i) { return i < 3 ? 5 : (i < 6 ? 7 : i); }
 // column col of Y = [Ac | Bc | bc] is non-zero in rows 0 .. yrow_(col)
 __host__ __device__ constexpr int yrow_(int col) { return col < 8 ? ge_(col) : 7; }
+// Hessian of the Lagrangian of the collocation equations in c_k: second derivatives of the kinematic rows over
+// (s, n, mu, vx, vy), of the dynamic rows over (vx, vy, r, delta), and the diagonal barrier terms of the bounds
+__host__ __device__ constexpr bool hnz_(int i, int j) { return (i <= 4 && j <= 4) || (i >= 3 && i <= 6 && j >= 3 && j <= 6) || i == j; }
 __host__ __device__ constexpr int imin_(int x, int y) { return x < y ? x : y; }
 __host__ __device__ constexpr int imax_(int x, int y) { return x > y ? x : y; }
 
@@ -590,7 +593,8 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     for (int col = 0; col < 11; col++) {
       double s = 0.0;
 #pragma unroll
-      for (int l = 0; l <= yrow_(col); l++) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
+      for (int l = 0; l <= yrow_(col); l++)
+        if (hnz_(i, l)) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
       HY[i * 11 + col] = s;
     }
   // Q = Ac^T Hc Ac, S = Bc^T Hc Ac, R = Bc^T Hc Bc + Du; q = [Ac|Bc]^T (Hc bc + gc0 + mu gc1) (+ gub)
@@ -1640,7 +1644,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
     double s = S.gc0[i] + mu * S.gc1[i];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      s += sym_get(S.Hc, i, j) * dc[j];
+      if (hnz_(i, j)) s += sym_get(S.Hc, i, j) * dc[j];
       if (i >= elo_(j) && i <= ehi_(j)) s += 2.0 * S.E1[j * 8 + i] * pi[j];
     }
     v[i] = -s;
@@ -1968,20 +1972,19 @@ __global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
 // ------------------------------------------------------------------------------------------ k_step1
 // Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
 // and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
-__global__ void __launch_bounds__(320) k_step1(Consts K, Work W) {  // 320 = 7 candidates x 40 intervals in one pass
+__global__ void __launch_bounds__(320) k_step1(Consts K, Work W) {  // 320 = 8 candidates x 40 intervals in one pass
   if ((int)blockIdx.x >= W.nact[0]) return;
   const int b = W.act[blockIdx.x];
   const int N = W.N, tid = threadIdx.x;
   const int* si = W.si;
   if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
-  for (int kk = tid; kk < N; kk += 320) d_linesearch(K, W, kk, b, 1, 1);
+  // all step candidates at once (the threads are there anyway; the wide path evaluates candidates 2.. only for the
+  // instances that rejected the full step, with the same arithmetic)
+  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
   __syncthreads();
   if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
   __syncthreads();
   if (si[(size_t)SI_LSMORE * W.Bp + b]) {  // block-uniform (written before the barrier)
-    const int nc = K.o.n_linesearch - 1;
-    for (int idx = tid; idx < N * nc; idx += 320) d_linesearch(K, W, idx % N, b, 2 + idx / N, 2 + idx / N);
-    __syncthreads();
     if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
     __syncthreads();
   }
