@@ -32,13 +32,6 @@ __device__ __forceinline__ double tsum8(E8Lds& L, const int i, const double* v) 
   for (int j = 0; j < 8; j++) s += L.vec[j * 8 + i];
   return s;
 }
-// element i (run-time) of a register array: selects instead of an indexed (scratch) access
-__device__ __forceinline__ double sel8(const double* a, const int i) {
-  double r = a[0];
-#pragma unroll
-  for (int j = 1; j < 8; j++) r = (i == j) ? a[j] : r;
-  return r;
-}
 // every lane of the slot contributes one value, all get the vector
 __device__ __forceinline__ void share8(E8Lds& L, const int i, const double mine, double* all) {
   WAVE_SYNC();

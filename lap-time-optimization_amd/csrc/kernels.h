@@ -1253,6 +1253,13 @@ struct Stage1Regs {
 // Stage data of the ONE instance of a k_riccati1 block, staged in LDS once per launch: with a single wavefront per
 // instance the sweep is a chain of N dependent stages, and fetching each stage from HBM/L2 (even one stage ahead) costs
 // more than the stage's arithmetic.  q: [N][QP_NF] (copy of the instance's QP blocks), u: [N][2], kk: [N][22] gains.
+// element i (run-time) of a register array: selects instead of an indexed (scratch) access
+__device__ __forceinline__ double sel8(const double* a, const int i) {
+  double r = a[0];
+#pragma unroll
+  for (int j = 1; j < 8; j++) r = (i == j) ? a[j] : r;
+  return r;
+}
 struct StageLds {  // views into the dynamic LDS of a k_riccati1 block
   double* q;   // [N][QP_NF]
   double* u;   // [N][2]
@@ -1416,49 +1423,68 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       const double Rm[3] = {cur.R[0], cur.R[1], cur.R[2]}, rr[2] = {cur.r[0], cur.r[1]};
       const double uk[2] = {cur.u[0], cur.u[1]}, vk[2] = {cur.v[0], cur.v[1]};
       const double* qk = S.q + k * QP_NF;  // A_k, B_k, b_k are read in place
-      // 1. element (i, g) of P A, element (i, g < 2) of P B, P b + p (same expressions as d_riccati8, one column per lane)
+      // 1. element (i, g) of P A, element (i, g < 2) of P B, P b + p (same expressions as d_riccati8, one column per lane).
+      //    Every phase first pulls what it needs from LDS into registers, branch-free, and then computes: a wave waits
+      //    once per phase instead of once per operand.
+      double Ag[8], Bg[8], bl[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) Ag[l] = qk[QP_A + l * 8 + g], Bg[l] = qk[QP_B + l * 2 + (g & 1)], bl[l] = qk[QP_b + l];
       double pa = 0.0, pb = 0.0, Pbi = ppi;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        pa += Prow[l] * qk[QP_A + l * 8 + g];
-        if (g < 2) pb += Prow[l] * qk[QP_B + l * 2 + g];
-        Pbi += Prow[l] * qk[QP_b + l];
+        pa += Prow[l] * Ag[l];
+        pb += Prow[l] * Bg[l];  // (lanes g >= 2 repeat column g & 1 and drop it)
+        Pbi += Prow[l] * bl[l];
       }
       L.PA[i * 8 + g] = pa;
       if (g < 2) L.PB[i * 2 + g] = pb;
       L.Pb[i] = Pbi;
       WAVE_SYNC();
       // 2. element (i, g) of Hxx, row i of Hux^T, gx_i
+      double Ai[8], PAg[8], PAi[8], B0[8], B1[8], X0[8], X1[8], Pbv[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        Ai[l] = qk[QP_A + l * 8 + i], PAg[l] = L.PA[l * 8 + g], PAi[l] = L.PA[l * 8 + i];
+        B0[l] = qk[QP_B + l * 2], B1[l] = qk[QP_B + l * 2 + 1], X0[l] = L.Pxv[l * 2], X1[l] = L.Pxv[l * 2 + 1];
+        Pbv[l] = L.Pb[l];
+      }
       double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        double ali = qk[QP_A + l * 8 + i];
-        hxx += ali * L.PA[l * 8 + g];
-        double pali = L.PA[l * 8 + i];
-        Hxu[0] += qk[QP_B + l * 2] * pali + L.Pxv[l * 2] * ali;
-        Hxu[1] += qk[QP_B + l * 2 + 1] * pali + L.Pxv[l * 2 + 1] * ali;
-        gx += ali * L.Pb[l];
+        double ali = Ai[l];
+        hxx += ali * PAg[l];
+        double pali = PAi[l];
+        Hxu[0] += B0[l] * pali + X0[l] * ali;
+        Hxu[1] += B1[l] * pali + X1[l] * ali;
+        gx += ali * Pbv[l];
       }
-      // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles
-      // (selects instead of run-time indices into the small arrays: an indexed array lives in scratch, and on gfx9 a
-      //  scratch reload waits on vmcnt, i.e. for every RC store of the previous stage to be acknowledged)
-      double he = 0.0;
-      if (g < 4) {
-        const int c = g >> 1, d = g & 1;
-        const double rm = (c + d == 0) ? Rm[0] : ((c + d == 1) ? Rm[1] : Rm[2]);  // Rm[sidx(c, d)]
-        const double pvv = c ? (d ? Pvv[3] : Pvv[2]) : (d ? Pvv[1] : Pvv[0]);     // Pvv[c * 2 + d]
+      // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles.
+      //    Both sums are formed by every lane with selected operands (no divergent branches, no run-time indices into
+      //    register arrays: those would live in scratch, and a scratch reload waits for the RC stores of the stage before)
+      double he;
+      {
+        const bool c1 = (g >> 1) & 1, d1 = g & 1;
+        const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);     // Rm[sidx(c, d)]
+        const double pvv = c1 ? (d1 ? Pvv[3] : Pvv[2]) : (d1 ? Pvv[1] : Pvv[0]);  // Pvv[c * 2 + d]
+        double PBd[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) PBd[l] = L.PB[l * 2 + (g & 1)];
         double s = rm + pvv;
 #pragma unroll
-        for (int l = 0; l < 8; l++)
-          s += qk[QP_B + l * 2 + c] * L.PB[l * 2 + d] + qk[QP_B + l * 2 + c] * L.Pxv[l * 2 + d] + L.Pxv[l * 2 + c] * qk[QP_B + l * 2 + d];
-        he = s;
-        if (c == d) he += (c ? r2[1] : r2[0]) + delta_w;
-      } else if (g < 6) {
-        const int c = g - 4;
-        double s = (c ? rr[1] : rr[0]) + (c ? r2[1] : r2[0]) * ((c ? uk[1] : uk[0]) - (c ? vk[1] : vk[0])) + (c ? pv[1] : pv[0]);
+        for (int l = 0; l < 8; l++) {
+          const double Bc = c1 ? B1[l] : B0[l], Bd = d1 ? B1[l] : B0[l], Xc = c1 ? X1[l] : X0[l], Xd = d1 ? X1[l] : X0[l];
+          s += Bc * PBd[l] + Bc * Xd + Xc * Bd;
+        }
+        double heH = s;
+        if (c1 == d1) heH += (c1 ? r2[1] : r2[0]) + delta_w;
+        // gu[c], c = g & 1
+        double sg = (d1 ? rr[1] : rr[0]) + (d1 ? r2[1] : r2[0]) * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);
 #pragma unroll
-        for (int l = 0; l < 8; l++) s += qk[QP_B + l * 2 + c] * L.Pb[l] + L.Pxv[l * 2 + c] * qk[QP_b + l];
-        he = s;
+        for (int l = 0; l < 8; l++) {
+          const double Bc = d1 ? B1[l] : B0[l], Xc = d1 ? X1[l] : X0[l];
+          sg += Bc * Pbv[l] + Xc * bl[l];
+        }
+        he = g < 4 ? heH : (g < 6 ? sg : 0.0);
       }
       double Huu[4], gu[2];
 #pragma unroll
