@@ -389,7 +389,7 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
   const double l1_i = 2.0 * (pi_i + tsum8(L, i, v));
   // slack / multiplier steps, fraction to the boundary, directional derivative of the barrier objective
   const double dxp_i = sel8(dxp, i);
-  double a_pri = 1.0, a_dua = 1.0, gphid = S.gcost * dxp_i;
+  double r_pri = 0.0, a_dua = 1.0, gphid = S.gcost * dxp_i;  // r_pri = max(-dt / t), see d_expand
   if (i < 2) {
     const double ui = i == 0 ? S.u[0] : S.u[1], dui = i == 0 ? du[0] : du[1];
     const double v0 = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
@@ -400,13 +400,13 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
     if (j != i) return;
     const double xv = kind == 0 ? (j == 0 ? S.u[0] : S.u[1]) : (kind == 1 ? S.c_i : S.xp_i);
     const double dv = kind == 0 ? (j == 0 ? du[0] : du[1]) : (kind == 1 ? dc_i : dxp_i);
-    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
     const double dtt = -(sg * (xv - val) + t) - sg * dv;
-    const double dn = (mu - nu * dtt) / t - nu;
+    const double dn = (mu - nu * dtt) * it - nu;
     if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-    if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+    r_pri = fmax(r_pri, -dtt * it);
     if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-    gphid -= mu * dtt / t;
+    gphid -= mu * dtt * it;
   });
   if (i < 3) {  // lane q handles track constraint q
     const int m = S.m_nl + i;
@@ -415,18 +415,19 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
       const double gsq = i == 0 ? S.gs[0] : (i == 1 ? S.gs[1] : S.gs[2]);
       const double gnq = i == 0 ? S.gn[0] : (i == 1 ? S.gn[1] : S.gn[2]);
       const double gmq = i == 0 ? S.gm[0] : (i == 1 ? S.gm[1] : S.gm[2]);
-      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
       const double dtt = -(gvq + t) - (gsq * dxp[0] + gnq * dxp[1] + gmq * dxp[2]);
-      const double dn = (mu - nu * dtt) / t - nu;
+      const double dn = (mu - nu * dtt) * it - nu;
       if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-      if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+      r_pri = fmax(r_pri, -dtt * it);
       if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-      gphid -= mu * dtt / t;
+      gphid -= mu * dtt * it;
     } else if (live) {
       PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
     }
   }
-  a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
+  r_pri = grp_max(r_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
+  const double a_pri = r_pri > tau ? tau / r_pri : 1.0;
   if (!live) return;
   PL(W.dC, i, k, N) = dc_i;
   PL(W.nL1, i, k, N) = l1_i, PL(W.nL2, i, k, N) = l2_i;

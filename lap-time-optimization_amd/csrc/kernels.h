@@ -1691,7 +1691,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
     PL(W.nL2, i, k, N) = v[i];
   }
   // slack / multiplier steps, fraction to the boundary, directional derivative of the barrier objective
-  double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
+  double r_pri = 0.0, a_dua = 1.0, gphid = 0.0;  // r_pri = max(-dt / t) over the slot's inequalities
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     double v0 = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
@@ -1706,29 +1706,30 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
-    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
     const double dtt = -(sg * (xv - val) + t) - sg * dv;
-    const double dn = (mu - nu * dtt) / t - nu;
+    const double dn = (mu - nu * dtt) * it - nu;
     PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-    if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+    r_pri = fmax(r_pri, -dtt * it);  // fraction to the boundary: alpha <= tau t / (-dt) for dt < 0, i.e. tau / max(-dt / t)
     if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-    gphid -= mu * dtt / t;
+    gphid -= mu * dtt * it;
   });
 #pragma unroll
   for (int q = 0; q < 3; q++) {
     const int m = S.m_nl + q;
     if (S.nl) {
-      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N);
+      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
       const double dtt = -(S.gv[q] + t) - (S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
-      const double dn = (mu - nu * dtt) / t - nu;
+      const double dn = (mu - nu * dtt) * it - nu;
       PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-      if (dtt < 0.0) a_pri = fmin(a_pri, -tau * t / dtt);
+      r_pri = fmax(r_pri, -dtt * it);
       if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-      gphid -= mu * dtt / t;
+      gphid -= mu * dtt * it;
     } else {
       PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
     }
   }
+  const double a_pri = r_pri > tau ? tau / r_pri : 1.0;
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
 
