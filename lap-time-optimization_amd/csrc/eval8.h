@@ -323,9 +323,9 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
   PG(W.QP, QP_b + i, k, QP_NF) = S.ABr[10];
 #pragma unroll
   for (int j = 0; j < 8; j++)
-    if (j <= i) PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) = T[j], PG(W.QP, QP_Qx + sidx(i, j), k, QP_NF) = S.Hxr[j];
+    if (j <= i) PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) = T[j], PG(W.QP, QP_Qx + sidx(i, j), k + 1, QP_NF) = S.Hxr[j];
   PG(W.QP, QP_q0 + i, k, QP_NF) = q0, PG(W.QP, QP_q1 + i, k, QP_NF) = q1;
-  PG(W.QP, QP_qx0 + i, k, QP_NF) = S.gx0, PG(W.QP, QP_qx1 + i, k, QP_NF) = S.gx1;
+  PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gx0, PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gx1;
   if (i < 2) {
 #pragma unroll
     for (int j = 0; j < 8; j++) PG(W.QP, QP_S + i * 8 + j, k, QP_NF) = Tu[j];

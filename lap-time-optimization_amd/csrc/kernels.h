@@ -37,7 +37,9 @@ enum : int {
   QP_q1 = 151,         // 8
   QP_r0 = 159,         // 2
   QP_r1 = 161,         // 2
-  QP_Qx = 163,         // 36  node block of x_{k+1} (cost + constraints + bounds + lambda2-weighted dynamics)
+  QP_Qx = 163,         // 36  node block of x_k (cost + constraints + bounds + lambda2-weighted dynamics): written by
+                       //     interval k-1 into THIS block, so that stage k of the Riccati sweep reads block k only;
+                       //     block N holds the terminal node only, the node part of block 0 is never written (zeros)
   QP_qx0 = 199,        // 8
   QP_qx1 = 207,        // 8
   QP_NF = 215
@@ -617,9 +619,9 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     else PG(W.QP, QP_r0 + i - 8, k, QP_NF) = s0 + S.gub0[i - 8], PG(W.QP, QP_r1 + i - 8, k, QP_NF) = s1 + S.gub1[i - 8];
   }
 #pragma unroll
-  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k, QP_NF) = S.Hxp[i];
+  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k + 1, QP_NF) = S.Hxp[i];
 #pragma unroll
-  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k, QP_NF) = S.gxp1[i];
+  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
 }
 
 __global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
@@ -704,8 +706,8 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) P[i * 8 + j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
-      pp[i] = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
+      for (int j = 0; j < 8; j++) P[i * 8 + j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);
+      pp[i] = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
       Pxv[i * 2] = Pxv[i * 2 + 1] = 0.0;
     }
     Pvv[0] = Pvv[1] = Pvv[2] = Pvv[3] = 0.0, pv[0] = pv[1] = 0.0;
@@ -781,13 +783,13 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           double s = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) + ((i == j) ? delta_w : 0.0);
-          if (k > 0) s += PG(W.QP, QP_Qx + sidx(i, j), k - 1, QP_NF);
+          if (k > 0) s += PG(W.QP, QP_Qx + sidx(i, j), k, QP_NF);
 #pragma unroll
           for (int l = 0; l < 8; l++) s += A[l * 8 + i] * PA[l * 8 + j];
           Hxx[i * 8 + j] = s;
         }
         double s = PG(W.QP, QP_q0 + i, k, QP_NF) + mu * PG(W.QP, QP_q1 + i, k, QP_NF);
-        if (k > 0) s += PG(W.QP, QP_qx0 + i, k - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k - 1, QP_NF);
+        if (k > 0) s += PG(W.QP, QP_qx0 + i, k, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k, QP_NF);
 #pragma unroll
         for (int l = 0; l < 8; l++) s += A[l * 8 + i] * Pb[l];
         gx[i] = s;
@@ -942,10 +944,10 @@ __device__ __forceinline__ void load_stage(const Consts& K, const Work& W, int b
   s.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), s.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
   s.b = PG(W.QP, QP_b + i, k, QP_NF);
 #pragma unroll
-  for (int j = 0; j < 8; j++) qa[j] = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF), qb[j] = PG(W.QP, QP_Qx + sidx(i, j), km, QP_NF);
+  for (int j = 0; j < 8; j++) qa[j] = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF), qb[j] = PG(W.QP, QP_Qx + sidx(i, j), k, QP_NF);
   s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
   const double q0 = PG(W.QP, QP_q0 + i, k, QP_NF), q1 = PG(W.QP, QP_q1 + i, k, QP_NF);
-  const double x0 = PG(W.QP, QP_qx0 + i, km, QP_NF), x1 = PG(W.QP, QP_qx1 + i, km, QP_NF);
+  const double x0 = PG(W.QP, QP_qx0 + i, k, QP_NF), x1 = PG(W.QP, QP_qx1 + i, k, QP_NF);
   s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
   const double r00 = PG(W.QP, QP_r0 + 0, k, QP_NF), r01 = PG(W.QP, QP_r0 + 1, k, QP_NF);
   const double r10 = PG(W.QP, QP_r1 + 0, k, QP_NF), r11 = PG(W.QP, QP_r1 + 1, k, QP_NF);
@@ -1057,8 +1059,8 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N - 1, QP_NF) + ((i == j) ? delta_w : 0.0);
-    ppi = PG(W.QP, QP_qx0 + i, N - 1, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N - 1, QP_NF);
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);
+    ppi = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
     pxv[0] = pxv[1] = 0.0;
     if (live) {
 #pragma unroll
@@ -1274,14 +1276,13 @@ __device__ __forceinline__ void load_stage1(const StageLds& S, const double p0, 
   const int km = k > 0 ? k - 1 : 0;
   const double wn = k > 0 ? 1.0 : 0.0;
   const double* q = S.q + k * QP_NF;
-  const double* qm = S.q + km * QP_NF;
   s.a = q[QP_A + i * 8 + g];
   s.bb = q[QP_B + i * 2 + (g & 1)];
   s.b = q[QP_b + i];
-  const double qa = q[QP_Q + sidx(i, g)], qb = qm[QP_Qx + sidx(i, g)];
+  const double qa = q[QP_Q + sidx(i, g)], qb = q[QP_Qx + sidx(i, g)];
   s.S[0] = q[QP_S + i], s.S[1] = q[QP_S + 8 + i];
   const double q0 = q[QP_q0 + i], q1 = q[QP_q1 + i];
-  const double x0 = qm[QP_qx0 + i], x1 = qm[QP_qx1 + i];
+  const double x0 = q[QP_qx0 + i], x1 = q[QP_qx1 + i];
   s.R[0] = q[QP_R + 0], s.R[1] = q[QP_R + 1], s.R[2] = q[QP_R + 2];
   const double r00 = q[QP_r0 + 0], r01 = q[QP_r0 + 1];
   const double r10 = q[QP_r1 + 0], r11 = q[QP_r1 + 1];
@@ -1404,8 +1405,8 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
 #pragma unroll
-    for (int j = 0; j < 8; j++) Prow[j] = S.q[(N - 1) * QP_NF + QP_Qx + sidx(i, j)] + ((i == j) ? delta_w : 0.0);
-    ppi = S.q[(N - 1) * QP_NF + QP_qx0 + i] + mu * S.q[(N - 1) * QP_NF + QP_qx1 + i];
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);  // (terminal node: not staged)
+    ppi = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
     pxv[0] = pxv[1] = 0.0;
     if (live) {
 #pragma unroll

@@ -247,7 +247,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.dC, 8 * N * Bp), rc |= h->dalloc(&W.dU, 2 * N * Bp);
   rc |= h->dalloc(&W.nL1, 8 * N * Bp), rc |= h->dalloc(&W.nL2, 8 * N * Bp);
   rc |= h->dalloc(&W.dT, ni * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
-  rc |= h->dalloc(&W.QP, (size_t)QP_NF * N * Bp), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
+  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
   rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp);
   rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp);
   rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);
@@ -565,7 +565,7 @@ long long ltompc_debug_fetch(ltompc_handle h, int which, void* out, long long nb
   const size_t N = h->N, Bp = h->Bp, ni = h->K.bd.ni;
   const Work& W = h->W;
   const void* src[15] = {W.QP, W.RC, W.RS, W.SP, W.LS, W.dX, W.dU, W.dC, W.dT, W.dNU, W.nL1, W.nL2, W.st, W.si, W.DBG};
-  const size_t sz[15] = {QP_NF * N * Bp * 8, RC_NF * (N + 1) * Bp * 8, RS_NF * N * Bp * 8, SP_NF * N * Bp * 8,
+  const size_t sz[15] = {QP_NF * (N + 1) * Bp * 8, RC_NF * (N + 1) * Bp * 8, RS_NF * N * Bp * 8, SP_NF * N * Bp * 8,
                          3 * ((size_t)h->K.o.n_linesearch + 1) * N * Bp * 8, 8 * (N + 1) * Bp * 8, 2 * N * Bp * 8, 8 * N * Bp * 8,
                          ni * N * Bp * 8, ni * N * Bp * 8, 8 * N * Bp * 8, 8 * N * Bp * 8, (size_t)ST_NF * Bp * 8, (size_t)SI_NF * Bp * 4,
                          W.DBG ? 8 * N * Bp * 8 : 0};

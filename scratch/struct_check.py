@@ -6,7 +6,7 @@ B, N = 8, 10
 x0 = ltompc.sample_x0(T, B)
 o = ltompc.default_options(); o.max_iter = 3; o.latency_mode = 2
 m = ltompc.BatchedMPC(T, N, B, options=o); m.set_initial_guess(x0); m.make_step(x0)
-qp = m.debug_fetch(0).reshape(N, 8, 215, 8)   # [k][b/8][field][b%8], Bp = 64
+qp = m.debug_fetch(0).reshape(N + 1, 8, 215, 8)[:N]   # [k][b/8][field][b%8], Bp = 64
 A = qp[:, 0, 0:64, :].reshape(N, 8, 8, 8)     # [k][i][j][b]
 Bm = qp[:, 0, 64:80, :].reshape(N, 8, 2, 8)
 np.set_printoptions(linewidth=200, precision=3, suppress=True)
