@@ -901,9 +901,12 @@ __global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) 
 // and the row-exchanged products (P A, P B, P b + p, K, P) live in LDS as [field][g] (conflict-free: a
 // wave-wide ds_read_b64 touches 8 or 64 consecutive doubles).  Same arithmetic as k_riccati.
 struct RicLds {
-  double A[64][8], B[16][8], b[8][8];
-  double PA[64][8], PB[16][8], Pb[8][8], K[16][8], P[64][8], Pxv[16][8];
-};
+  // The stage blocks of the wavefront's 8 instances, double-buffered, as [field][g] (the layout of the QP buffer, so the
+  // A, B, b the products need are read in place): lane (g, i) fetches fields i, i + 8, ... of instance g one stage
+  // ahead (27 loads per lane instead of the 45 values a lane needs itself, and no second register set for them).
+  double sb[2][(QP_NF + 1) * 8];  // 27 x 8 fields: lane row 7 fetches one field past the block (padding, never read)
+  double PA[64][8], PB[16][8], Pb[8][8], K[16][8], Pxv[16][8];  // (the new P is exchanged through PA: P A is dead by then)
+};  // 35.2 kB: four wavefronts per CU
 
 __device__ __forceinline__ double grp_max(double v) {  // over the 8 lanes of an instance (lane stride 8)
   v = fmax(v, __shfl_xor(v, 8)), v = fmax(v, __shfl_xor(v, 16)), v = fmax(v, __shfl_xor(v, 32));
@@ -1055,6 +1058,8 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
   // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
   // once only the stragglers are left
+  constexpr int NPF = (QP_NF + 7) / 8;  // fields a lane fetches per stage block
+  const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
   for (int sweep = 0;; sweep++) {
     bool ok = true;
     double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
@@ -1071,35 +1076,50 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
     }
     WAVE_SYNC();
     L.Pxv[i * 2][g] = 0.0, L.Pxv[i * 2 + 1][g] = 0.0;
-    StageRegs cur;
-    load_stage(K, W, b, i, N - 1, mu, delta_w, cur);
+    // stage N-1 into buffer (N-1) & 1; inputs u_k, u_{k-1} ride along in registers
+    double pf[NPF];
+    {
+      const double* src = &PG(W.QP, i, N - 1, QP_NF);  // fields i, i + 8, ...: 64 doubles apart
+#pragma unroll
+      for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NPF; j++) L.sb[(N - 1) & 1][(i + 8 * j) * 8 + g] = pf[j];
+    double uk[2] = {PL(W.U, 0, N - 1, N), PL(W.U, 1, N - 1, N)};
+    double vk[2];
+    {
+      const int km = N - 2 > 0 ? N - 2 : 0;
+      const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
+      vk[0] = N - 1 > 0 ? v0 : up0, vk[1] = N - 1 > 0 ? v1 : up1;
+    }
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
-      // stage k was fetched one stage ahead (registers cur); fetch stage k-1 now so that its latency hides
-      // behind this stage's arithmetic
-      StageRegs nxt = cur;
-      if (k > 0) load_stage(K, W, b, i, k - 1, mu, delta_w, nxt);
-      double Arow[8], Brow[2], Qrow[8], Scol[2], Rm[3], rr[2], uk[2], vk[2];
+      // fetch stage k-1 now (branch-free: for k = 0 block 0 is fetched again and dropped), written to the other LDS
+      // buffer at the end of this stage, so that its latency hides behind this stage's arithmetic
+      const int kn = k > 0 ? k - 1 : 0, kv = k > 1 ? k - 2 : 0;
+      const double vn0 = PL(W.U, 0, kv, N), vn1 = PL(W.U, 1, kv, N);
+      WAVE_SYNC();  // the stage block written at the end of the previous stage is visible
+      const double* q = L.sb[k & 1];
+      const double wn = k > 0 ? 1.0 : 0.0;  // the node block of x_0 does not exist (x_0 is data; its slot holds zeros)
+      double Qrow[8], Scol[2], Rm[3], rr[2];
 #pragma unroll
-      for (int j = 0; j < 8; j++) Arow[j] = cur.A[j], Qrow[j] = cur.Q[j];
-      Brow[0] = cur.B[0], Brow[1] = cur.B[1];
-      const double bi = cur.b, qi = cur.q;
-      Scol[0] = cur.S[0], Scol[1] = cur.S[1];
-      Rm[0] = cur.R[0], Rm[1] = cur.R[1], Rm[2] = cur.R[2];
-      rr[0] = cur.r[0], rr[1] = cur.r[1], uk[0] = cur.u[0], uk[1] = cur.u[1], vk[0] = cur.v[0], vk[1] = cur.v[1];
-      WAVE_SYNC();  // previous stage's readers of L.A / L.B / L.b / L.K are done
-#pragma unroll
-      for (int j = 0; j < 8; j++) L.A[i * 8 + j][g] = Arow[j];
-      L.B[i * 2][g] = Brow[0], L.B[i * 2 + 1][g] = Brow[1], L.b[i][g] = bi;
-      WAVE_SYNC();
+      for (int j = 0; j < 8; j++)
+        Qrow[j] = q[(QP_Q + sidx(i, j)) * 8 + g] + ((i == j) ? delta_w : 0.0) + wn * q[(QP_Qx + sidx(i, j)) * 8 + g];
+      Scol[0] = q[(QP_S + i) * 8 + g], Scol[1] = q[(QP_S + 8 + i) * 8 + g];
+      const double qi = q[(QP_q0 + i) * 8 + g] + mu * q[(QP_q1 + i) * 8 + g] + wn * (q[(QP_qx0 + i) * 8 + g] + mu * q[(QP_qx1 + i) * 8 + g]);
+      Rm[0] = q[(QP_R + 0) * 8 + g], Rm[1] = q[(QP_R + 1) * 8 + g], Rm[2] = q[(QP_R + 2) * 8 + g];
+      rr[0] = q[(QP_r0 + 0) * 8 + g] + mu * q[(QP_r1 + 0) * 8 + g], rr[1] = q[(QP_r0 + 1) * 8 + g] + mu * q[(QP_r1 + 1) * 8 + g];
+#define LA(x) q[(QP_A + (x)) * 8 + g]
+#define LB(x) q[(QP_B + (x)) * 8 + g]
+#define Lb(x) q[(QP_b + (x)) * 8 + g]
       // 1. row i of P A, P B, P b + p
       double PAr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, PBr[2] = {0, 0}, Pbi = ppi;
 #pragma unroll
       for (int l = 0; l < 8; l++) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) PAr[j] += Prow[l] * L.A[l * 8 + j][g];
-        PBr[0] += Prow[l] * L.B[l * 2][g], PBr[1] += Prow[l] * L.B[l * 2 + 1][g];
-        Pbi += Prow[l] * L.b[l][g];
+        for (int j = 0; j < 8; j++) PAr[j] += Prow[l] * LA(l * 8 + j);
+        PBr[0] += Prow[l] * LB(l * 2), PBr[1] += Prow[l] * LB(l * 2 + 1);
+        Pbi += Prow[l] * Lb(l);
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = PAr[j];
@@ -1112,13 +1132,19 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
       Hxu[0] = Scol[0], Hxu[1] = Scol[1];
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        double ali = L.A[l * 8 + i][g];
+        double ali = LA(l * 8 + i);
 #pragma unroll
         for (int j = 0; j < 8; j++) Hxx[j] += ali * L.PA[l * 8 + j][g];
         double pali = L.PA[l * 8 + i][g];
-        Hxu[0] += L.B[l * 2][g] * pali + L.Pxv[l * 2][g] * ali;
-        Hxu[1] += L.B[l * 2 + 1][g] * pali + L.Pxv[l * 2 + 1][g] * ali;
+        Hxu[0] += LB(l * 2) * pali + L.Pxv[l * 2][g] * ali;
+        Hxu[1] += LB(l * 2 + 1) * pali + L.Pxv[l * 2 + 1][g] * ali;
         gx += ali * L.Pb[l][g];
+      }
+      // (the next stage block is requested here: its 27 registers per lane are live for half a stage only)
+      {
+        const double* src = &PG(W.QP, i, kn, QP_NF);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
       }
       // 3. Huu, gu (same numbers in the 8 lanes of an instance)
       double Huu[4], gu[2];
@@ -1129,15 +1155,18 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
           double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
 #pragma unroll
           for (int l = 0; l < 8; l++)
-            s += L.B[l * 2 + c][g] * L.PB[l * 2 + d][g] + L.B[l * 2 + c][g] * L.Pxv[l * 2 + d][g] + L.Pxv[l * 2 + c][g] * L.B[l * 2 + d][g];
+            s += LB(l * 2 + c) * L.PB[l * 2 + d][g] + LB(l * 2 + c) * L.Pxv[l * 2 + d][g] + L.Pxv[l * 2 + c][g] * LB(l * 2 + d);
           Huu[c * 2 + d] = s;
         }
         Huu[c * 2 + c] += r2[c] + delta_w;
         double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
 #pragma unroll
-        for (int l = 0; l < 8; l++) s += L.B[l * 2 + c][g] * L.Pb[l][g] + L.Pxv[l * 2 + c][g] * L.b[l][g];
+        for (int l = 0; l < 8; l++) s += LB(l * 2 + c) * L.Pb[l][g] + L.Pxv[l * 2 + c][g] * Lb(l);
         gu[c] = s;
       }
+#undef LA
+#undef LB
+#undef Lb
       double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
       bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
       if (bad && live) ok = false;
@@ -1166,11 +1195,17 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
         pv[c] = gv[c] - r2[c] * kff[c];
       }
 #pragma unroll
-      for (int j = 0; j < 8; j++) L.P[i * 8 + j][g] = Pn[j];
+      for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = Pn[j];
       WAVE_SYNC();
 #pragma unroll
-      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? Pn[j] : 0.5 * (Pn[j] + L.P[j * 8 + i][g]);
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? Pn[j] : 0.5 * (Pn[j] + L.PA[j * 8 + i][g]);
       L.Pxv[i * 2][g] = pxv[0], L.Pxv[i * 2 + 1][g] = pxv[1];  // read after the next stage's first barrier
+      // the stage block fetched above goes to the other buffer (last read one stage ago), BEFORE this stage's stores
+      // are issued: waiting for the loads then does not wait for the stores
+#pragma unroll
+      for (int j = 0; j < NPF; j++) L.sb[(k & 1) ^ 1][(i + 8 * j) * 8 + g] = pf[j];
+      uk[0] = vk[0], uk[1] = vk[1];  // u_{k-1} is the v of stage k
+      vk[0] = k > 1 ? vn0 : up0, vk[1] = k > 1 ? vn1 : up1;
       if (live) {
         PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
         if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
@@ -1183,7 +1218,6 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
           PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
         }
       }
-      cur = nxt;
     }
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
     const bool failed = live && !ok;
@@ -1211,36 +1245,62 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
     STI(SI_STEP) = 1;
   }
   if (!__any(live)) return;
-  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
+  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles.  A_k, B_k, b_k (88
+  //      fields of the QP block) and the gains (22 fields of the RC block) are staged like the blocks of the sweep.
   double dxi = 0.0, dv[2] = {0.0, 0.0};
   if (live) PL(W.dX, i, 0, N + 1) = 0.0;
-  FwdRegs fc;
-  load_fwd(W, b, i, 0, fc);
+  constexpr int NFQ = 11, NFR = 3, FK = 88;  // fields i + 8 j: 11 per lane of A, B, b; 3 per lane of K, Kv, kff (stored at FK..)
+  double fq[NFQ], fr[NFR];
+  {
+    const double* sq = &PG(W.QP, i, 0, QP_NF);
+    const double* sr = &PG(W.RC, i, 0, RC_NF);  // (row 7 reads fields 7, 15, 23: the last one is P, not a gain, never used)
+#pragma unroll
+    for (int j = 0; j < NFQ; j++) fq[j] = sq[j * 64];
+#pragma unroll
+    for (int j = 0; j < NFR; j++) fr[j] = sr[j * 64];
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < NFQ; j++) L.sb[0][(i + 8 * j) * 8 + g] = fq[j];
+#pragma unroll
+  for (int j = 0; j < NFR; j++) L.sb[0][(FK + i + 8 * j) * 8 + g] = fr[j];  // (FK + 22, FK + 23: unused slots)
 #pragma unroll 1
   for (int k = 0; k < N; k++) {
-    FwdRegs fn = fc;
-    if (k + 1 < N) load_fwd(W, b, i, k + 1, fn);
+    const int kn = k + 1 < N ? k + 1 : k;
+    {
+      const double* sq = &PG(W.QP, i, kn, QP_NF);
+      const double* sr = &PG(W.RC, i, kn, RC_NF);
+#pragma unroll
+      for (int j = 0; j < NFQ; j++) fq[j] = sq[j * 64];
+#pragma unroll
+      for (int j = 0; j < NFR; j++) fr[j] = sr[j * 64];
+    }
+    WAVE_SYNC();
+    const double* q = L.sb[k & 1];
     double dx[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
     double du[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
-      double s = fc.kff[c] + fc.Kv[c * 2] * dv[0] + fc.Kv[c * 2 + 1] * dv[1];
+      double s = q[(FK + 20 + c) * 8 + g] + q[(FK + 16 + c * 2) * 8 + g] * dv[0] + q[(FK + 16 + c * 2 + 1) * 8 + g] * dv[1];
 #pragma unroll
-      for (int j = 0; j < 8; j++) s += fc.K[c * 8 + j] * dx[j];
+      for (int j = 0; j < 8; j++) s += q[(FK + c * 8 + j) * 8 + g] * dx[j];
       du[c] = s;
     }
-    double s = fc.b + fc.B[0] * du[0] + fc.B[1] * du[1];
+    double s = q[(QP_b + i) * 8 + g] + q[(QP_B + i * 2) * 8 + g] * du[0] + q[(QP_B + i * 2 + 1) * 8 + g] * du[1];
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += fc.A[j] * dx[j];
+    for (int j = 0; j < 8; j++) s += q[(QP_A + i * 8 + j) * 8 + g] * dx[j];
     dxi = s;
     dv[0] = du[0], dv[1] = du[1];
+#pragma unroll
+    for (int j = 0; j < NFQ; j++) L.sb[(k & 1) ^ 1][(i + 8 * j) * 8 + g] = fq[j];
+#pragma unroll
+    for (int j = 0; j < NFR; j++) L.sb[(k & 1) ^ 1][(FK + i + 8 * j) * 8 + g] = fr[j];
     if (live) {
       PL(W.dX, i, k + 1, N + 1) = dxi;
       if (i < 2) PL(W.dU, i, k, N) = du[i];
     }
-    fc = fn;
   }
 #undef STD
 #undef STI

@@ -247,7 +247,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.dC, 8 * N * Bp), rc |= h->dalloc(&W.dU, 2 * N * Bp);
   rc |= h->dalloc(&W.nL1, 8 * N * Bp), rc |= h->dalloc(&W.nL2, 8 * N * Bp);
   rc |= h->dalloc(&W.dT, ni * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
-  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
+  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp + 64), rc |=  // (+64: k_riccati8 fetches one field past the last block)
+  h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
   rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp);
   rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp);
   rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);
