@@ -336,13 +336,15 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
 }
 
 // One wavefront = 8 slots (instances act[8 grp .. 8 grp + 7] of interval k) x 8 lanes.
-__global__ void __launch_bounds__(64) k_eval8(Consts K, Work W) {
+__global__ void __launch_bounds__(64) k_eval8(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   __shared__ E8Lds lds[8];
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int G8 = W.n_pad >> 3;
+  const int G8 = la.n_pad >> 3;
   const int k = blockIdx.x / G8, j = (blockIdx.x % G8) * 8 + g;
-  const bool valid = j < W.nact[0];
-  const int b = W.act[valid ? j : 0];
+  const bool valid = j < la.nact[0];
+  const int b = la.act[valid ? j : 0];
   const int* si = W.si;
   const bool live = valid && !si[(size_t)SI_DONE * W.Bp + b] && !si[(size_t)SI_RETRY * W.Bp + b] &&
                     !si[(size_t)SI_SKIP_EVAL * W.Bp + b];  // else: the blocks of the last launch are still valid
@@ -434,13 +436,15 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
   if (i == 0) PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
 
-__global__ void __launch_bounds__(64) k_expand8(Consts K, Work W) {
+__global__ void __launch_bounds__(64) k_expand8(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   __shared__ E8Lds lds[8];
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int G8 = W.n_pad >> 3;
+  const int G8 = la.n_pad >> 3;
   const int k = blockIdx.x / G8, j = (blockIdx.x % G8) * 8 + g;
-  const bool valid = j < W.nact[0];
-  const int b = W.act[valid ? j : 0];
+  const bool valid = j < la.nact[0];
+  const int b = la.act[valid ? j : 0];
   const int* si = W.si;
   const bool live = valid && !si[(size_t)SI_DONE * W.Bp + b] && si[(size_t)SI_STEP * W.Bp + b];  // else: no step this launch
   if (!__any(live)) return;

@@ -77,14 +77,17 @@ struct Work {
   double *filt;        // [2*FILTER_MAX][Bp]
   int *si;             // [SI_NF][Bp]
   int *active;         // [max_iter+2] number of unfinished instances after iteration i
-  // compaction of the unfinished instances: thread j of a launch works on instance act[j], j < nact[0] <= n_launch.
-  // The list is sorted (stable compaction), so while nothing has finished it is the identity and accesses coalesce.
-  const int* act;
-  const int* nact;
-  int n_launch, n_pad;  // n_pad = n_launch rounded up to a multiple of 64
   double* DBG;  // [8][N][Bp] scratch planes for debugging
   int *ls_list, *ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
-  int debug_extra_sweeps;
+};
+
+// What changes from launch to launch (kernel argument; Work and Consts are read from device memory).  Compaction of the
+// unfinished instances: thread j of a launch works on instance act[j], j < nact[0] <= the launch width.  The list is
+// sorted (stable compaction), so while nothing has finished it is the identity and accesses coalesce.
+struct Launch {
+  const int* act;
+  const int* nact;
+  int n_pad;  // launch width rounded up to a multiple of 64
 };
 
 struct Consts {
@@ -435,7 +438,9 @@ __device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8
 // ------------------------------------------------------------------------------------------ k_init
 // Cold: do_mpc set_initial_guess (every state slot = x0, inputs 0, multipliers 0).  Warm: keep the previous
 // primal/dual solution un-shifted (do_mpc), node 0 := new x0.  Slacks t = max(-h, bound_push), nu = mu/t.
-__global__ void k_init(Consts K, Work W, int cold) {
+__global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, int cold) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int b = tid % W.Bp, k = tid / W.Bp;
   const int N = W.N;
@@ -624,20 +629,24 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
 }
 
-__global__ void __launch_bounds__(64) k_eval(Consts K, Work W) {
+__global__ void __launch_bounds__(64) k_eval(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = tid % W.n_pad, k = tid / W.n_pad;
-  if (k >= W.N || j >= W.nact[0]) return;
-  d_eval(K, W, k, W.act[j]);
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_eval(K, W, k, la.act[j]);
 }
 
 // ------------------------------------------------------------------------------------------ k_riccati
 // One thread per instance.  State of the recursion is (x_k, v_k = u_{k-1}) because do_mpc's rterm penalises
 // u_k - u_{k-1} (controller.py:40-41): stage cost r |u_k - v_k|^2, v_{k+1} = u_k.
-__global__ void __launch_bounds__(64) k_riccati(Consts K, Work W, int it_index) {
+__global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int it_index) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= W.nact[0]) return;
-  const int b = W.act[j];
+  if (j >= la.nact[0]) return;
+  const int b = la.act[j];
   const int N = W.N;
   double* st = W.st;
   int* si = W.si;
@@ -1670,24 +1679,24 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
 #undef STI
 }
 
-__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, int it_index, int max_sweeps) {
+__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
   __shared__ RicLds L;
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   const int jj = blockIdx.x * 8 + g;
-  const bool valid = jj < W.nact[0];
-  d_riccati8(K, W, L, g, i, W.act[valid ? jj : 0], valid, it_index, max_sweeps);
+  const bool valid = jj < la.nact[0];
+  d_riccati8(K, W, L, g, i, la.act[valid ? jj : 0], valid, it_index, max_sweeps);
 }
 
 // One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
 // sweep, and 8 instances per wavefront make that sweep ~3x longer than it has to be).  Dynamic LDS: ric1_lds_bytes(N).
-__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, int it_index) {
+__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, Launch la, int it_index) {
   extern __shared__ double lds1[];
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  if ((int)blockIdx.x >= W.nact[0]) return;
+  if ((int)blockIdx.x >= la.nact[0]) return;
   const int N = W.N;
   StageLds S{lds1, lds1 + (size_t)N * QP_NF, lds1 + (size_t)N * (QP_NF + 2)};
   Ric1Lds& L = *reinterpret_cast<Ric1Lds*>(lds1 + (size_t)N * (QP_NF + 24));
-  d_riccati1(K, W, L, S, g, i, W.act[blockIdx.x], g == 0, it_index, 1);
+  d_riccati1(K, W, L, S, g, i, la.act[blockIdx.x], g == 0, it_index, 1);
 }
 
 // ------------------------------------------------------------------------------------------ k_expand
@@ -1794,11 +1803,11 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
 
-__global__ void __launch_bounds__(64) k_expand(Consts K, Work W) {
+__global__ void __launch_bounds__(64) k_expand(Consts K, Work W, Launch la) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int j = tid % W.n_pad, k = tid / W.n_pad;
-  if (k >= W.N || j >= W.nact[0]) return;
-  d_expand(K, W, k, W.act[j]);
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_expand(K, W, k, la.act[j]);
 }
 
 // ------------------------------------------------------------------------------------------ k_linesearch
@@ -1870,7 +1879,9 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   }
 }
 
-__global__ void __launch_bounds__(64, 2) k_linesearch(Consts K, Work W, int phase, int jw) {
+__global__ void __launch_bounds__(64, 2) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
   // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
   //          list of rejected instances; jw = launch width in instances, longer lists are covered grid-stride.
@@ -1878,9 +1889,9 @@ __global__ void __launch_bounds__(64, 2) k_linesearch(Consts K, Work W, int phas
   const int N = W.N;
   const int j0 = tid % jw, rest = tid / jw, k = rest % N, cand = rest / N;
   if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
-  const int count = phase == 0 ? W.nact[0] : W.ls_count[0];
+  const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
   const int l = phase == 0 ? 1 : 2 + cand;
-  for (int j = j0; j < count; j += jw) d_linesearch(K, W, k, phase == 0 ? W.act[j] : W.ls_list[j], l, l);
+  for (int j = j0; j < count; j += jw) d_linesearch(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
 }
 
 // ------------------------------------------------------------------------------------------ k_pick
@@ -2017,11 +2028,13 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   STI(SI_SKIP_EVAL) = (!take && !eps_switched) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
 }
 
-__global__ void __launch_bounds__(64) k_pick(Consts K, Work W, int phase) {
+__global__ void __launch_bounds__(64) k_pick(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   const int j = blockIdx.x * 8 + g;
-  if (j >= (phase == 0 ? W.nact[0] : W.ls_count[0])) return;
-  d_pick(K, W, phase == 0 ? W.act[j] : W.ls_list[j], i, phase, true);
+  if (j >= (phase == 0 ? la.nact[0] : W.ls_count[0])) return;
+  d_pick(K, W, phase == 0 ? la.act[j] : W.ls_list[j], i, phase, true);
 }
 
 // ------------------------------------------------------------------------------------------ k_update
@@ -2048,21 +2061,25 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
   }
 }
 
-__global__ void __launch_bounds__(64) k_update(Consts K, Work W) {
+__global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
-  int j = tid % W.n_pad, k = tid / W.n_pad;
-  if (k >= W.N || j >= W.nact[0]) return;
-  d_update(K, W, k, W.act[j]);
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_update(K, W, k, la.act[j]);
 }
 
 
 // ------------------------------------------------------------------------------------------ k_step1
 // Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
 // and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
-__global__ void __launch_bounds__(320) k_step1(Consts K, Work W) {  // 320 = 8 candidates x 40 intervals in one pass
-  if ((int)blockIdx.x >= W.nact[0]) return;
-  const int b = W.act[blockIdx.x];
+__global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {  // 320 = 8 candidates x 40 intervals in one pass
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  if ((int)blockIdx.x >= la.nact[0]) return;
+  const int b = la.act[blockIdx.x];
   const int N = W.N, tid = threadIdx.x;
   const int* si = W.si;
   if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform

@@ -62,6 +62,8 @@ struct ltompc_solver {
   int cur_width = 0;  // instances in the launches being issued
   double ms_by_kernel[NKERN] = {};
   int launches_by_kernel[NKERN] = {};
+  Consts* d_K = nullptr;  // device copies of K and W for the solver kernels
+  Work* d_W = nullptr;
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
@@ -275,6 +277,14 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   T.n = n_table;
   T.s_kappa = h->d_tables, T.kappa = h->d_tables + n_table, T.s_arc = h->d_tables + 2 * (size_t)n_table;
   T.n_left = h->d_tables + 3 * (size_t)n_table, T.n_right = h->d_tables + 4 * (size_t)n_table, T.v_ref = h->d_tables + 5 * (size_t)n_table;
+  // K is complete now: the solver kernels read it from device memory
+  if (h->dalloc(&h->d_K, 1) || h->dalloc(&h->d_W, 1) ||
+      hipMemcpyAsync(h->d_K, &h->K, sizeof(Consts), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(h->d_W, &h->W, sizeof(Work), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+      hipStreamSynchronize(h->stream) != hipSuccess) {
+    ltompc_destroy(h);
+    return fail("ltompc_create: upload of the constants failed");
+  }
   *out = h;
   return 0;
 }
@@ -316,7 +326,7 @@ int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev) {
   HIPCHECK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
   hipLaunchKernelGGL(k_zero_uprev, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W);
-  hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, 1);
+  hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, 1);
   HIPCHECK(hipGetLastError());
   h->cold_next = true;  // the next make_step starts from this guess
   return 0;
@@ -343,56 +353,52 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 0);
     hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 1);
   }
-  hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->K, h->W, h->cold_next ? 1 : 0);
+  hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
   HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, sizeof(int), h->stream));
   h->cold_next = false;
   // all instances unfinished: identity list
   int cur = 0, n_launch = B;
   hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_act[0], h->d_nact[0], B);
-  Work W = h->W;
-  {
-    const char* e = getenv("LTOMPC_DEBUG_SWEEPS");
-    W.debug_extra_sweeps = e ? atoi(e) : 0;
-  }
+  Launch la{};
   auto set_launch = [&](int n) {
     n_launch = n;
     h->cur_width = n;
-    W.act = h->d_act[cur], W.nact = h->d_nact[cur], W.n_launch = n, W.n_pad = (n + 63) / 64 * 64;
+    la.act = h->d_act[cur], la.nact = h->d_nact[cur], la.n_pad = (n + 63) / 64 * 64;
   };
   set_launch(B);
   h->last_compactions = 0;
   h->history.clear();
   int it = 0;
   for (;; it++) {
-    const int np = W.n_pad;
-    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->K, W) : L.run(0, k_eval, N * np, h->K, W)) return -1;
+    const int np = la.n_pad;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, k_eval, N * np, h->d_K, h->d_W, la)) return -1;
     if (h->serial_riccati) {
-      if (L.run(1, k_riccati, np, h->K, W, it)) return -1;
+      if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
     } else {
       // measured: letting the stragglers retry inside a launch (max_sweeps 4 when n_launch <= 256) finishes them in
       // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
       const int max_sweeps = 1;
       if (n_launch <= h->ric1_width) {
         L.lds = ric1_lds_bytes(N);
-        if (L.run(6, k_riccati1, n_launch * 64, h->K, W, it)) return -1;  // one wavefront per instance
-      } else if (L.run(1, k_riccati8, np * 8, h->K, W, it, max_sweeps)) return -1;  // 8 lanes per instance
+        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it)) return -1;  // one wavefront per instance
+      } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->K, W) : L.run(2, k_expand, N * np, h->K, W)) return -1;
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, k_expand, N * np, h->K, h->W, la)) return -1;
     if (n_launch <= h->step1_width) {
       // one workgroup per instance does both line-search phases, the filter test and the update
       L.block_threads = 320;
-      if (L.run(7, k_step1, n_launch * 320, h->K, W)) return -1;
+      if (L.run(7, k_step1, n_launch * 320, h->d_K, h->d_W, la)) return -1;
     } else {
-      if (L.run(3, k_linesearch, N * np, h->K, W, 0, np)) return -1;
-      if (L.run(4, k_pick, np * 8, h->K, W, 0)) return -1;  // 8 lanes per instance
+      if (L.run(3, k_linesearch, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
+      if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
       if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
         const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
-        if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->K, W, 1, jw)) return -1;
-        if (L.run(4, k_pick, np * 8, h->K, W, 1)) return -1;
+        if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
+        if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 1)) return -1;
       }
-      if (L.run(5, k_update, N * np, h->K, W)) return -1;
+      if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;
     }
     if ((it + 1) % h->poll_every == 0) {
       if (L.close()) return -1;
