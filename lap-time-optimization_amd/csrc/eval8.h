@@ -120,6 +120,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
   S.Du = 0.0, S.gub0 = 0.0, S.gub1 = 0.0, S.dud = 0.0;
   S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
   double hcd = 0.0, hxd = 0.0;  // additions to the diagonal entries Hc[i][i], Hx+[i][i]
+  double lprod = 1.0;           // product of the slacks this lane owns (at most 6): one logarithm per lane
   S.m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
     if (j != i) return;
     const double xv = kind == 0 ? (j == 0 ? S.u[0] : S.u[1]) : (kind == 1 ? S.c_i : S.xp_i);
@@ -139,7 +140,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
     if (DUAL) {
       S.rp_ineq = fmax(S.rp_ineq, fabs(hv + t));
       S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-      S.th_ineq += fabs(hv + t), S.sumlog += log(t);
+      S.th_ineq += fabs(hv + t), lprod *= t;
     }
   });
   if (S.nl) {
@@ -161,10 +162,11 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
       if (DUAL && i == q) {
         S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
         S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-        S.th_ineq += fabs(S.gv[q] + t), S.sumlog += log(t);
+        S.th_ineq += fabs(S.gv[q] + t), lprod *= t;
       }
     }
   }
+  if (DUAL) S.sumlog = log(lprod);
 #pragma unroll
   for (int j = 0; j < 8; j++)
     if (j == i) S.Hcr[j] += hcd, S.Hxr[j] += hxd;

@@ -233,6 +233,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
   // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
   S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
+  double lprod = 1.0;  // sum of log t = log of products of 8 slacks (3 logarithms per slot, see d_linesearch)
   const int m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double hv = sg * (xv - val);
@@ -251,7 +252,8 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
     if (WITH_DUAL) {
       S.rp_ineq = fmax(S.rp_ineq, fabs(hv + t));
       S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-      S.th_ineq += fabs(hv + t), S.sumlog += log(t);
+      S.th_ineq += fabs(hv + t), lprod *= t;
+      if ((m & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
     }
   });
   S.m_nl = m_nl;
@@ -277,13 +279,15 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
       if (WITH_DUAL) {
         S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
         S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-        S.th_ineq += fabs(S.gv[q] + t), S.sumlog += log(t);
+        S.th_ineq += fabs(S.gv[q] + t), lprod *= t;
+        if ((mm & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
       }
     }
   } else {
 #pragma unroll
     for (int q = 0; q < 3; q++) S.gv[q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
   }
+  if (WITH_DUAL) S.sumlog += log(lprod);
 }
 
 // Elimination of the collocation point: with M8 = 4.5 I + 2 E2 E1,
@@ -1860,11 +1864,13 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
     double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
 #pragma unroll
     for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
-    double sl = 0.0;
+    // sum of log t as the log of products of 8 slacks (same grouping in linearise_slot): 3 logarithms instead of 23
+    double sl = 0.0, pr = 1.0;
     const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
       const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
       const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
-      th += fabs(sg * (xv - val) + t), sl += log(t);
+      th += fabs(sg * (xv - val) + t), pr *= t;
+      if ((mm & 7) == 7) sl += log(pr), pr = 1.0;
     });
     if (nl) {
       double gv[3];
@@ -1872,9 +1878,11 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
-        th += fabs(gv[q] + t), sl += log(t);
+        th += fabs(gv[q] + t), pr *= t;
+        if (((m + q) & 7) == 7) sl += log(pr), pr = 1.0;
       }
     }
+    sl += log(pr);
     PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
   }
 }
