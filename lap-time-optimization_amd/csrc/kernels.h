@@ -104,48 +104,6 @@ struct Consts {
 #define PG(base, f, k, NF) ((base)[(((size_t)(k) * (W.Bp >> 3) + (b >> 3)) * (NF) + (f)) * 8 + (b & 7)])
 
 // ------------------------------------------------------------------------------------------ small dense LA
-__device__ __forceinline__ bool lu8(double* M) {  // in place, no pivoting (M = 4.5 I + 2 E2 E1); diagonal: 1 / pivot
-  bool ok = true;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    double pv = M[k * 8 + k];
-    ok = ok && (fabs(pv) > 1e-12);
-    double ip = 1.0 / pv;
-    M[k * 8 + k] = ip;  // the solves multiply by the reciprocal pivot (8 divisions per factorisation instead of 8 per solve)
-#pragma unroll
-    for (int i = k + 1; i < 8; i++) {
-      double l = M[i * 8 + k] * ip;
-      M[i * 8 + k] = l;
-#pragma unroll
-      for (int j = k + 1; j < 8; j++) M[i * 8 + j] -= l * M[k * 8 + j];
-    }
-  }
-  return ok;
-}
-__device__ __forceinline__ void lu8_solve(const double* M, double* v) {
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-#pragma unroll
-    for (int i = k + 1; i < 8; i++) v[i] -= M[i * 8 + k] * v[k];
-#pragma unroll
-  for (int i = 7; i >= 0; i--) {
-#pragma unroll
-    for (int j = i + 1; j < 8; j++) v[i] -= M[i * 8 + j] * v[j];
-    v[i] *= M[i * 8 + i];
-  }
-}
-__device__ __forceinline__ void lu8_solve_t(const double* M, double* v) {  // M^T x = v
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-#pragma unroll
-    for (int j = 0; j < i; j++) v[i] -= M[j * 8 + i] * v[j];
-    v[i] *= M[i * 8 + i];
-  }
-#pragma unroll
-  for (int i = 7; i >= 0; i--)
-#pragma unroll
-    for (int j = i + 1; j < 8; j++) v[i] -= M[j * 8 + i] * v[j];
-}
 __device__ __forceinline__ double sym_get(const double* H, int i, int j) { return H[sidx(i, j)]; }
 
 
@@ -944,52 +902,9 @@ __device__ __forceinline__ double grp_min(double v) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
-struct StageRegs {  // what lane (g,i) needs of stage k
-  double A[8], B[2], b, Q[8], S[2], q, R[3], r[2], u[2], v[2];
-};
-__device__ __forceinline__ void load_stage(const Consts& K, const Work& W, int b, int i, int k, double mu, double delta_w,
-                                           StageRegs& s) {
-  const int N = W.N;
-  // branch-free: the node block of x_k lives in slot k-1; for k = 0 (x_0 is data) slot 0 is read and weighted by 0,
-  // so that all ~45 loads of a stage are issued back to back and waited for once
-  const int km = k > 0 ? k - 1 : 0;
-  const double wn = k > 0 ? 1.0 : 0.0;
-  double qa[8], qb[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) s.A[j] = PG(W.QP, QP_A + i * 8 + j, k, QP_NF);
-  s.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), s.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
-  s.b = PG(W.QP, QP_b + i, k, QP_NF);
-#pragma unroll
-  for (int j = 0; j < 8; j++) qa[j] = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF), qb[j] = PG(W.QP, QP_Qx + sidx(i, j), k, QP_NF);
-  s.S[0] = PG(W.QP, QP_S + i, k, QP_NF), s.S[1] = PG(W.QP, QP_S + 8 + i, k, QP_NF);
-  const double q0 = PG(W.QP, QP_q0 + i, k, QP_NF), q1 = PG(W.QP, QP_q1 + i, k, QP_NF);
-  const double x0 = PG(W.QP, QP_qx0 + i, k, QP_NF), x1 = PG(W.QP, QP_qx1 + i, k, QP_NF);
-  s.R[0] = PG(W.QP, QP_R + 0, k, QP_NF), s.R[1] = PG(W.QP, QP_R + 1, k, QP_NF), s.R[2] = PG(W.QP, QP_R + 2, k, QP_NF);
-  const double r00 = PG(W.QP, QP_r0 + 0, k, QP_NF), r01 = PG(W.QP, QP_r0 + 1, k, QP_NF);
-  const double r10 = PG(W.QP, QP_r1 + 0, k, QP_NF), r11 = PG(W.QP, QP_r1 + 1, k, QP_NF);
-  s.u[0] = PL(W.U, 0, k, N), s.u[1] = PL(W.U, 1, k, N);
-  const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
-  const double p0 = W.uprev[b], p1 = W.uprev[(size_t)W.Bp + b];
-#pragma unroll
-  for (int j = 0; j < 8; j++) s.Q[j] = qa[j] + ((i == j) ? delta_w : 0.0) + wn * qb[j];
-  s.q = q0 + mu * q1 + wn * (x0 + mu * x1);
-  s.r[0] = r00 + mu * r10, s.r[1] = r01 + mu * r11;
-  s.v[0] = k > 0 ? v0 : p0, s.v[1] = k > 0 ? v1 : p1;
-}
 struct FwdRegs {
   double K[16], Kv[4], kff[2], A[8], B[2], b;
 };
-__device__ __forceinline__ void load_fwd(const Work& W, int b, int i, int k, FwdRegs& f) {
-#pragma unroll
-  for (int j = 0; j < 16; j++) f.K[j] = PG(W.RC, RC_K + j, k, RC_NF);
-#pragma unroll
-  for (int j = 0; j < 4; j++) f.Kv[j] = PG(W.RC, RC_Kv + j, k, RC_NF);
-  f.kff[0] = PG(W.RC, RC_kff + 0, k, RC_NF), f.kff[1] = PG(W.RC, RC_kff + 1, k, RC_NF);
-#pragma unroll
-  for (int j = 0; j < 8; j++) f.A[j] = PG(W.QP, QP_A + i * 8 + j, k, QP_NF);
-  f.B[0] = PG(W.QP, QP_B + i * 2, k, QP_NF), f.B[1] = PG(W.QP, QP_B + i * 2 + 1, k, QP_NF);
-  f.b = PG(W.QP, QP_b + i, k, QP_NF);
-}
 
 // All 64 lanes of a wavefront call this together; lane (g, i) works on row i of instance b (padding lanes: valid =
 // false, they shadow a real instance read-only).  active_slot >= 0: count the unfinished instances there.
