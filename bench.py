@@ -200,6 +200,26 @@ def main():
         extras["batch1_ms_per_solve"] = 1e3 * t_solve / nb
         extras["batch1_iters_last"] = int(m1.iters[0])
         m1.close()
+        # BASELINE config 5 (closed loop from the reference's x0, horizon N = 60): real-time factor over the first 300
+        # ticks (30 s of driving, s = 0 .. ~290 m; the formulation does not get through the narrowest section of the
+        # track at s ~ 416 m, so a whole lap is not a meaningful workload)
+        o60 = ltompc.default_options()
+        o60.max_iter = 300
+        m60 = ltompc.BatchedMPC(tables, n_horizon=60, batch=1, options=o60, device=local_rank)
+        m60.set_stream(stream.cuda_stream)
+        x60 = ltompc.X0_REFERENCE[None].copy()
+        m60.set_initial_guess(x60)
+        t60, bad60, it60 = 0.0, 0, 0
+        for _ in range(300):
+            tb = time.perf_counter()
+            u60 = m60.make_step(x60)
+            t60 += time.perf_counter() - tb
+            bad60 += int(m60.status[0] != 0)
+            it60 += int(m60.iters[0])
+            x60 = m60.plant_step(x60, u60)
+        extras["closed_loop_n60"] = {"ticks": 300, "simulated_s": 30.0, "solve_wall_s": t60, "real_time_factor": 30.0 / t60,
+                                     "s_reached_m": float(x60[0, 0]), "non_converged_ticks": bad60, "ip_iters_mean": it60 / 300.0}
+        m60.close()
 
     # ---- same workload with the warm start tuned for MPC (extension, not the reference's solver settings): previous
     #      solution shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same
