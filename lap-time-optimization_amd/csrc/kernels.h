@@ -67,26 +67,26 @@ enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_S
 struct Work {
   int N, B, Bp;
   // iterate
-  double *X, *C, *U, *L1, *L2, *T, *NU;
+  gptr<double> X, C, U, L1, L2, T, NU;
   // steps
-  double *dX, *dC, *dU, *nL1, *nL2, *dT, *dNU;
+  gptr<double> dX, dC, dU, nL1, nL2, dT, dNU;
   // buffers
-  double *QP, *RC, *RS, *SP, *LS;
-  double *x0, *uprev;  // [8][Bp], [2][Bp]
-  double *st;          // [ST_NF][Bp]
-  double *filt;        // [2*FILTER_MAX][Bp]
-  int *si;             // [SI_NF][Bp]
-  int *active;         // [max_iter+2] number of unfinished instances after iteration i
-  double* DBG;  // [8][N][Bp] scratch planes for debugging
-  int *ls_list, *ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
+  gptr<double> QP, RC, RS, SP, LS;
+  gptr<double> x0, uprev;  // [8][Bp], [2][Bp]
+  gptr<double> st;     // [ST_NF][Bp]
+  gptr<double> filt;   // [2*FILTER_MAX][Bp]
+  gptr<int> si;        // [SI_NF][Bp]
+  gptr<int> active;    // [max_iter+2] number of unfinished instances after iteration i
+  gptr<double> DBG;  // [8][N][Bp] scratch planes for debugging
+  gptr<int> ls_list, ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
 };
 
 // What changes from launch to launch (kernel argument; Work and Consts are read from device memory).  Compaction of the
 // unfinished instances: thread j of a launch works on instance act[j], j < nact[0] <= the launch width.  The list is
 // sorted (stable compaction), so while nothing has finished it is the identity and accesses coalesce.
 struct Launch {
-  const int* act;
-  const int* nact;
+  gptr<const int> act;
+  gptr<const int> nact;
   int n_pad;  // launch width rounded up to a multiple of 64
 };
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "kernels.h"
@@ -69,15 +70,17 @@ struct ltompc_solver {
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
-  template <typename T>
-  int dalloc(T** p, size_t n) {
+  // (P may be a gptr<T>: a global-address-space pointer in the device pass of the compiler, a plain one on the host)
+  template <typename P>
+  int dalloc(P* p, size_t n) {
+    using T = std::remove_pointer_t<P>;
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, n * sizeof(T));
     if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
     e = hipMemsetAsync(q, 0, n * sizeof(T), stream);
     if (e != hipSuccess) return fail(std::string("hipMemset: ") + hipGetErrorString(e));
     allocs.push_back(q);
-    *p = static_cast<T*>(q);
+    *p = (P)q;
     return 0;
   }
 };
@@ -275,8 +278,9 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   }
   Tables& T = h->K.T;
   T.n = n_table;
-  T.s_kappa = h->d_tables, T.kappa = h->d_tables + n_table, T.s_arc = h->d_tables + 2 * (size_t)n_table;
-  T.n_left = h->d_tables + 3 * (size_t)n_table, T.n_right = h->d_tables + 4 * (size_t)n_table, T.v_ref = h->d_tables + 5 * (size_t)n_table;
+  using tp = gptr<const double>;
+  T.s_kappa = (tp)h->d_tables, T.kappa = (tp)(h->d_tables + n_table), T.s_arc = (tp)(h->d_tables + 2 * (size_t)n_table);
+  T.n_left = (tp)(h->d_tables + 3 * (size_t)n_table), T.n_right = (tp)(h->d_tables + 4 * (size_t)n_table), T.v_ref = (tp)(h->d_tables + 5 * (size_t)n_table);
   // K is complete now: the solver kernels read it from device memory
   if (h->dalloc(&h->d_K, 1) || h->dalloc(&h->d_W, 1) ||
       hipMemcpyAsync(h->d_K, &h->K, sizeof(Consts), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -364,7 +368,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   auto set_launch = [&](int n) {
     n_launch = n;
     h->cur_width = n;
-    la.act = h->d_act[cur], la.nact = h->d_nact[cur], la.n_pad = (n + 63) / 64 * 64;
+    la.act = (gptr<const int>)h->d_act[cur], la.nact = (gptr<const int>)h->d_nact[cur], la.n_pad = (n + 63) / 64 * 64;
   };
   set_launch(B);
   h->last_compactions = 0;

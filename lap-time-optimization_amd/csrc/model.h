@@ -29,14 +29,18 @@ constexpr int MAX_NI = MAX_UB + 2 * MAX_XB + NNL;
 // index of (i,j), i >= j, in a packed lower-triangular symmetric matrix
 __host__ __device__ constexpr int sidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
+// Device pointers are typed as global-address-space pointers in device code: the kernels that read Consts / Work from
+// device memory (instead of kernel arguments) would otherwise see generic pointers and use flat_load / flat_store
+// (slower, and counted by the LDS wait counter as well).  Same size and layout on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> using gptr = __attribute__((address_space(1))) T*;
+#else
+template <class T> using gptr = T*;
+#endif
+
 struct Tables {
   int n;
-  const double* s_kappa;
-  const double* kappa;
-  const double* s_arc;
-  const double* n_left;
-  const double* n_right;
-  const double* v_ref;
+  gptr<const double> s_kappa, kappa, s_arc, n_left, n_right, v_ref;
 };
 
 struct Bounds {
