@@ -234,8 +234,10 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     if (t) h->ric1_width = atoi(t);
     // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
     if (ric1_lds_bytes(n_horizon) > 150 * 1024) h->ric1_width = 0;
+    // (the attribute belongs to the kernel, not to the handle: always the cap, so that handles with different horizons
+    //  do not lower each other's limit)
     else if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_riccati1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)ric1_lds_bytes(n_horizon)) != hipSuccess) {
+                                 150 * 1024) != hipSuccess) {
       (void)hipGetLastError();
       h->ric1_width = 0;
     }

@@ -356,3 +356,16 @@ def test_latency_mode_kernels_agree(pkg, tables, oracle, gpu_lib):
     ref = oracle.solve(x0, N, nthreads=8)
     both = ok & (ref["status"] == 0)
     assert np.abs(b["u0"] - ref["u0"])[both].max() < 1e-6
+
+
+def test_handles_with_different_horizons_coexist(pkg, tables, oracle, gpu_lib):
+    """Per-kernel attributes (dynamic LDS of k_riccati1) must not depend on which handle was created last."""
+    x = pkg.X0_REFERENCE[None].copy()
+    a = pkg.BatchedMPC(tables, 60, 1)
+    b = pkg.BatchedMPC(tables, 10, 1)
+    a.set_initial_guess(x); b.set_initial_guess(x)
+    ub = b.make_step(x)
+    ua = a.make_step(x)   # 116 kB of LDS per workgroup after a handle that needs 20 kB was created
+    assert a.status[0] == 0 and b.status[0] == 0
+    assert np.abs(ua - oracle.solve(x, 60)["u0"]).max() < 1e-7 and np.abs(ub - oracle.solve(x, 10)["u0"]).max() < 1e-7
+    a.close(); b.close()
