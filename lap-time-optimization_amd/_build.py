@@ -7,7 +7,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libltompc.so")
-SOURCES = ["ltompc.hip", "kernels.h", "model.h", os.path.join("..", "..", "include", "ltompc.h"), os.path.join("..", "_build.py")]
+SOURCES = ["ltompc.hip"] + sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "ltompc.h"), os.path.join("..", "_build.py")]
 
 
 def needs_build() -> bool:

@@ -1,0 +1,246 @@
+// aux_kernels.h — initial point, warm-start shift, list compaction, I/O, plant step, test hooks.
+#pragma once
+#include "linearise.h"
+
+namespace ltompc {
+
+// ------------------------------------------------------------------------------------------ k_init
+// Cold: do_mpc set_initial_guess (every state slot = x0, inputs 0, multipliers 0).  Warm: keep the previous
+// primal/dual solution un-shifted (do_mpc), node 0 := new x0.  Slacks t = max(-h, bound_push), nu = mu/t.
+__global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, int cold) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k >= N || b >= W.B) return;
+  double x0[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
+  if (k == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.X, i, 0, N + 1) = x0[i];
+  }
+  if (cold) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PL(W.X, i, k + 1, N + 1) = x0[i], PL(W.C, i, k, N) = x0[i];
+      PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
+    }
+    PL(W.U, 0, k, N) = 0.0, PL(W.U, 1, k, N) = 0.0;
+  }
+  // Option warm_reset_on_fail: the multipliers of a solve that did not converge are not worth starting from (they are
+  // what diverged): keep its primal point, restart the equality multipliers at 0 and the barrier at the cold mu_init.
+  const int prev = W.si[(size_t)SI_PREV * W.Bp + b];
+  const bool after_failure = !cold && K.o.warm_reset_on_fail && prev != LTOMPC_STATUS_SOLVED && prev != LTOMPC_STATUS_ACCEPTABLE;
+  if (after_failure) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
+  }
+  double xp[8], c[8], u[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xp[i] = cold ? x0[i] : PL(W.X, i, k + 1, N + 1), c[i] = cold ? x0[i] : PL(W.C, i, k, N);
+  u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
+  const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
+  const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
+  // (flat visitor, no nested by-reference lambdas: see d_expand)
+  const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
+    const double hv = sg * (xv - val);
+    const double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
+    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
+  });
+  double gv[3] = {-1.0, -1.0, -1.0};
+  if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+  for (int q = 0; q < 3; q++) {
+    const double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push;
+    PL(W.T, m + q, k, N) = t, PL(W.NU, m + q, k, N) = mu / t;
+  }
+  if (k == 0) {
+    double* st = W.st;
+    st[(size_t)ST_MU * W.Bp + b] = mu, st[(size_t)ST_EPS * W.Bp + b] = eps, st[(size_t)ST_EPS_NEXT * W.Bp + b] = eps;
+    st[(size_t)ST_DW_LAST * W.Bp + b] = 0.0, st[(size_t)ST_FORCE_REG * W.Bp + b] = 0.0;
+    st[(size_t)ST_ALPHA * W.Bp + b] = 0.0, st[(size_t)ST_ADUA * W.Bp + b] = 0.0;
+    st[(size_t)ST_E0 * W.Bp + b] = 1e300, st[(size_t)ST_OBJ * W.Bp + b] = 0.0, st[(size_t)ST_TAU * W.Bp + b] = 0.99;
+    st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
+    st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
+    st[(size_t)ST_C00 * W.Bp + b] = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
+    for (int i = 0; i < SI_NF; i++)
+      if (i != SI_PREV) W.si[(size_t)i * W.Bp + b] = 0;
+    W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ k_shift
+// Option warm_shift: previous solution moved one interval ahead (x_k <- x_{k+1}, c/u/multipliers likewise, the last
+// interval repeated).  Two passes through the step buffers so that no thread reads what another one overwrites.
+__global__ void k_shift(Work W, int pass) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  const int N = W.N;
+  if (k > N || b >= W.B) return;
+  if (pass == 0) {
+    const int kx = k + 1 <= N ? k + 1 : N, ks = k + 1 <= N - 1 ? k + 1 : N - 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.dX, i, k, N + 1) = PL(W.X, i, kx, N + 1);
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        PL(W.dC, i, k, N) = PL(W.C, i, ks, N);
+        PL(W.nL1, i, k, N) = PL(W.L1, i, ks, N), PL(W.nL2, i, k, N) = PL(W.L2, i, ks, N);
+      }
+      PL(W.dU, 0, k, N) = PL(W.U, 0, ks, N), PL(W.dU, 1, k, N) = PL(W.U, 1, ks, N);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.X, i, k, N + 1) = PL(W.dX, i, k, N + 1);
+    if (k < N) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        PL(W.C, i, k, N) = PL(W.dC, i, k, N);
+        PL(W.L1, i, k, N) = PL(W.nL1, i, k, N), PL(W.L2, i, k, N) = PL(W.nL2, i, k, N);
+      }
+      PL(W.U, 0, k, N) = PL(W.dU, 0, k, N), PL(W.U, 1, k, N) = PL(W.dU, 1, k, N);
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------ compaction
+__global__ void k_act_identity(int* act, int* nact, int B) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) act[b] = b;
+  if (b == 0) nact[0] = B;
+}
+// Stable compaction of the unfinished instances of `src[0..nsrc)` into `dst`; one workgroup of 1024 threads.
+__global__ void __launch_bounds__(1024) k_compact(const int* __restrict__ src, const int* __restrict__ nsrc_p,
+                                                   const int* __restrict__ done, int* __restrict__ dst, int* __restrict__ ndst) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, nsrc = nsrc_p[0];
+  const int chunk = (nsrc + 1023) / 1024, lo = t * chunk, hi = min(nsrc, lo + chunk);
+  int c = 0;
+  for (int j = lo; j < hi; j++) c += done[src[j]] ? 0 : 1;
+  cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+    int v = t >= off ? cnt[t - off] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  int pos = cnt[t] - c;
+  for (int j = lo; j < hi; j++) {
+    int b = src[j];
+    if (!done[b]) dst[pos++] = b;
+  }
+  if (t == 1023) ndst[0] = cnt[1023];
+}
+
+// ------------------------------------------------------------------------------------------ I/O helpers
+// row-major (B x 8) user buffer -> [8][Bp] planes
+__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+#pragma unroll
+  for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[(size_t)b * 8 + i];
+  W.si[(size_t)SI_PREV * W.Bp + b] = W.si[(size_t)SI_STATUS * W.Bp + b];  // k_init resets the rest
+}
+__global__ void k_zero_uprev(Work W) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  W.uprev[b] = 0.0, W.uprev[(size_t)W.Bp + b] = 0.0;
+}
+// u0 = U[:,0,:] -> row-major (B x 2) and u_prev := u0 (do_mpc: _u_prev = last returned u0)
+__global__ void k_store_u0(Work W, double* __restrict__ u0_rm) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  const int N = W.N;
+  double a = PL(W.U, 0, 0, N), c = PL(W.U, 1, 0, N);
+  if (u0_rm) u0_rm[(size_t)b * 2] = a, u0_rm[(size_t)b * 2 + 1] = c;
+  W.uprev[b] = a, W.uprev[(size_t)W.Bp + b] = c;
+}
+
+// plant: classical RK4 with n_sub sub-steps, zero-order-hold input (do_mpc Simulator / CVODES stand-in)
+__global__ void k_plant(Consts K, int B, const double* __restrict__ x, const double* __restrict__ u, double dt,
+                        int n_sub, double* __restrict__ xn) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double y[8], uu[2] = {u[(size_t)b * 2], u[(size_t)b * 2 + 1]};
+#pragma unroll
+  for (int i = 0; i < 8; i++) y[i] = x[(size_t)b * 8 + i];
+  const double hs = dt / n_sub;
+  for (int s = 0; s < n_sub; s++) {
+    double k1[8], k2[8], k3[8], k4[8], z[8];
+    rhs_val(K.p, K.T, 0.0, y, uu, k1);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + 0.5 * hs * k1[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + 0.5 * hs * k2[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k3);
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = y[i] + hs * k3[i];
+    rhs_val(K.p, K.T, 0.0, z, uu, k4);
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] += hs / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = y[i];
+}
+
+__global__ void k_slip_forces(Consts K, int B, const double* __restrict__ x, double* __restrict__ alpha,
+                              double* __restrict__ Fy) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const ltompc_params& p = K.p;
+  const double* xb = x + (size_t)b * 8;
+  double af = atan2(xb[4] + p.length_f * xb[5], xb[3]) - xb[6];
+  double ar = atan2(xb[4] - p.length_r * xb[5], xb[3]);
+  double L = p.length_f + p.length_r;
+  double Fnf = p.length_r * p.mass * p.gravity / L, Fnr = p.length_f * p.mass * p.gravity / L;
+  alpha[(size_t)b * 2] = af, alpha[(size_t)b * 2 + 1] = ar;
+  Fy[(size_t)b * 2] = -Fnf * p.D_f * sin(p.C_f * atan(p.B_f * af));
+  Fy[(size_t)b * 2 + 1] = -Fnr * p.D_r * sin(p.C_r * atan(p.B_r * ar));
+}
+
+// test hooks: model derivatives at given points (thread = point)
+__global__ void k_test_model(Consts K, int n, double eps, const double* __restrict__ x, const double* __restrict__ lam,
+                             double* __restrict__ f, double* __restrict__ J, double* __restrict__ H,
+                             double* __restrict__ cval, double* __restrict__ cgrad, double* __restrict__ cH,
+                             double* __restrict__ gval, double* __restrict__ ggrad, double* __restrict__ gH) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double xx[8], ll[8], ff[8], JJ[48], HH[36];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xx[i] = x[(size_t)t * 8 + i], ll[i] = lam[(size_t)t * 8 + i];
+#pragma unroll
+  for (int i = 0; i < 36; i++) HH[i] = 0.0;
+  rhs_derivs(K.p, K.T, eps, xx, ff, JJ, ll, 1.0, HH);
+  for (int i = 0; i < 6; i++) f[(size_t)t * 8 + i] = ff[i];
+  f[(size_t)t * 8 + 6] = f[(size_t)t * 8 + 7] = 0.0;
+  for (int i = 0; i < 48; i++) J[(size_t)t * 64 + i] = JJ[i];
+  for (int i = 48; i < 64; i++) J[(size_t)t * 64 + i] = 0.0;
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) H[(size_t)t * 64 + i * 8 + j] = HH[sidx(i, j)];
+  for (int term = 0; term < 2; term++) {
+    double g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, Hc[36];
+    for (int i = 0; i < 36; i++) Hc[i] = 0.0;
+    cval[(size_t)t * 2 + term] = cost_eval(K.p, K.T, eps, xx, term == 1, g, Hc);
+    for (int i = 0; i < 8; i++) {
+      cgrad[((size_t)t * 2 + term) * 8 + i] = g[i];
+      for (int j = 0; j < 8; j++) cH[((size_t)t * 2 + term) * 64 + i * 8 + j] = Hc[sidx(i, j)];
+    }
+  }
+  double gv[3], gs[3], gn[3], gm[3], hss[3], hmm[3];
+  cons_eval(K.p, K.T, eps, xx, gv, gs, gn, gm, hss, hmm);
+  for (int q = 0; q < 3; q++) {
+    gval[(size_t)t * 3 + q] = gv[q];
+    for (int i = 0; i < 8; i++) ggrad[((size_t)t * 3 + q) * 8 + i] = 0.0;
+    ggrad[((size_t)t * 3 + q) * 8 + 0] = gs[q], ggrad[((size_t)t * 3 + q) * 8 + 1] = gn[q], ggrad[((size_t)t * 3 + q) * 8 + 2] = gm[q];
+    for (int i = 0; i < 64; i++) gH[((size_t)t * 3 + q) * 64 + i] = 0.0;
+    gH[((size_t)t * 3 + q) * 64 + 0] = hss[q], gH[((size_t)t * 3 + q) * 64 + 2 * 8 + 2] = hmm[q];
+  }
+}
+
+
+}  // namespace ltompc

@@ -1,6 +1,6 @@
 // Wave-cooperative evaluation kernels: 8 lanes per (interval, instance) slot, 8 slots per wavefront.
 //
-// The thread-per-slot kernels (k_eval / k_expand in kernels.h) keep ~450 doubles of one slot alive in one lane: 512
+// The thread-per-slot kernels (k_eval / k_expand in linearise.h) keep ~450 doubles of one slot alive in one lane: 512
 // registers per lane, one wavefront per SIMD, hundreds of spilled registers, and an in-order pipeline that shows the
 // full latency of every dependent fp64 operation (measured: 13 cycles per instruction, 22 % VALU-active).  Here lane
 // (g, i) owns ROW i of the slot's 8x8 blocks (g = slot in the wavefront), the model is evaluated once per lane (lanes
@@ -10,6 +10,7 @@
 // Same quantities as linearise_slot / condense_slot / d_eval / d_expand (the formulas are derived there); the
 // elimination of the collocation point uses a row-parallel Gauss-Jordan sweep instead of LU + substitutions.
 #pragma once
+#include "linearise.h"
 
 namespace ltompc {
 

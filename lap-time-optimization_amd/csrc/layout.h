@@ -1,0 +1,121 @@
+// layout.h — buffers, indices and shared helpers of the HIP kernels (see kernels.h for the overview).
+//
+// HBM layout: every per-(k,b) quantity of the iterate / step / partial arrays is a plane [field][k][Bp] with the
+// instance index fastest, so that the 64 lanes of a wavefront (consecutive b, same k) read/write 512 contiguous bytes
+// per field; the stage-QP and Riccati buffers are [k][b / 8][field][b % 8] (see PG below).
+#pragma once
+#include "model.h"
+
+namespace ltompc {
+
+
+constexpr int FILTER_MAX = 16;
+constexpr double DW_KEEP = 1e-5;  // regularisation below this is dropped to exactly 0
+constexpr int MAX_LS = 12;
+
+// fields of the stage-QP buffer written by k_eval and read by k_riccati
+enum : int {
+  QP_A = 0,            // 64  A_k   (dx+ = A dx + B du + b)
+  QP_B = 64,           // 16
+  QP_b = 80,           // 8
+  QP_Q = 88,           // 36  condensed-collocation part of the (x_k,x_k) block
+  QP_S = 124,          // 16  (u_k, x_k)
+  QP_R = 140,          // 3   (u_k, u_k) incl. input-bound barrier
+  QP_q0 = 143,         // 8   gradient = q0 + mu * q1
+  QP_q1 = 151,         // 8
+  QP_r0 = 159,         // 2
+  QP_r1 = 161,         // 2
+  QP_Qx = 163,         // 36  node block of x_k (cost + constraints + bounds + lambda2-weighted dynamics): written by
+                       //     interval k-1 into THIS block, so that stage k of the Riccati sweep reads block k only;
+                       //     block N holds the terminal node only, the node part of block 0 is never written (zeros)
+  QP_qx0 = 199,        // 8
+  QP_qx1 = 207,        // 8
+  QP_NF = 215
+};
+// fields of the Riccati buffer written by k_riccati and read by k_expand; stage index 0..N
+enum : int { RC_K = 0, RC_Kv = 16, RC_kff = 20, RC_P = 22, RC_Pxv = 58, RC_pp = 74, RC_NF = 82 };
+// residual partials written by k_eval (per k,b)
+enum : int { RS_rd = 0, RS_rp, RS_cmax, RS_cmin, RS_smult, RS_cost, RS_NF };
+// step partials written by k_expand
+enum : int { SP_apri = 0, SP_adua, SP_gphid, SP_NF };
+// per-instance double state
+enum : int {
+  ST_MU = 0, ST_EPS, ST_EPS_NEXT, ST_DW_LAST, ST_FORCE_REG, ST_ALPHA, ST_ADUA, ST_E0, ST_OBJ, ST_TAU,
+  ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY,
+  ST_C00,  // lterm(x_0) for the current ST_EPS: a constant of the solve between two changes of the table smoothing
+  ST_NF
+};
+// per-instance int state
+// SI_LSMORE: the full step was rejected by the filter test, the remaining step candidates have to be evaluated.
+// SI_RETRY: the last Riccati sweep failed the inertia test; the next launch repeats it with ST_DW_TRY (no new
+// evaluation).  SI_SKIP_EVAL: the iterate did not move (failed line search), k_eval's output is still valid.
+enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
+             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
+
+struct Work {
+  int N, B, Bp;
+  // iterate
+  gptr<double> X, C, U, L1, L2, T, NU;
+  // steps
+  gptr<double> dX, dC, dU, nL1, nL2, dT, dNU;
+  // buffers
+  gptr<double> QP, RC, RS, SP, LS;
+  gptr<double> x0, uprev;  // [8][Bp], [2][Bp]
+  gptr<double> st;     // [ST_NF][Bp]
+  gptr<double> filt;   // [2*FILTER_MAX][Bp]
+  gptr<int> si;        // [SI_NF][Bp]
+  gptr<int> active;    // [max_iter+2] number of unfinished instances after iteration i
+  gptr<double> DBG;  // [8][N][Bp] scratch planes for debugging
+  gptr<int> ls_list, ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
+};
+
+// What changes from launch to launch (kernel argument; Work and Consts are read from device memory).  Compaction of the
+// unfinished instances: thread j of a launch works on instance act[j], j < nact[0] <= the launch width.  The list is
+// sorted (stable compaction), so while nothing has finished it is the identity and accesses coalesce.
+struct Launch {
+  gptr<const int> act;
+  gptr<const int> nact;
+  int n_pad;  // launch width rounded up to a multiple of 64
+};
+
+struct Consts {
+  ltompc_params p;
+  ltompc_options o;
+  Tables T;
+  Bounds bd;
+};
+
+#define PL(base, f, k, NK) ((base)[((size_t)(f) * (NK) + (k)) * W.Bp + b])
+// Stage-QP and Riccati buffers: [k][b / 8][field][b % 8].  A wavefront of k_riccati8 (8 instances x 8 lanes, lane
+// (g,i) touching field f0 + i of instance g) then reads/writes 512 contiguous bytes per instruction, and the
+// thread-per-(k,b) kernels still move whole 64-byte sectors (8 consecutive instances of one field).
+#define PG(base, f, k, NF) ((base)[(((size_t)(k) * (W.Bp >> 3) + (b >> 3)) * (NF) + (f)) * 8 + (b & 7)])
+
+
+// per-instance scalars: `st` / `si` are local copies of W.st / W.si in the functions that use these
+#define STD(f) st[(size_t)(f) * W.Bp + b]
+#define STI(f) si[(size_t)(f) * W.Bp + b]
+
+// no s_barrier and, unlike __syncthreads(), must not drain the outstanding global loads/stores (vmcnt): only the
+// compiler has to keep the LDS accesses in order.
+#define WAVE_SYNC()                                        \
+  do {                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); \
+    __builtin_amdgcn_wave_barrier();                       \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
+  } while (0)
+
+__device__ __forceinline__ double grp_max(double v) {  // over the 8 lanes of an instance (lane stride 8)
+  v = fmax(v, __shfl_xor(v, 8)), v = fmax(v, __shfl_xor(v, 16)), v = fmax(v, __shfl_xor(v, 32));
+  return v;
+}
+__device__ __forceinline__ double grp_sum(double v) {
+  v += __shfl_xor(v, 8), v += __shfl_xor(v, 16), v += __shfl_xor(v, 32);
+  return v;
+}
+__device__ __forceinline__ double grp_min(double v) {
+  v = fmin(v, __shfl_xor(v, 8)), v = fmin(v, __shfl_xor(v, 16)), v = fmin(v, __shfl_xor(v, 32));
+  return v;
+}
+
+}  // namespace ltompc

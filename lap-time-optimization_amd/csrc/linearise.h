@@ -1,0 +1,517 @@
+// linearise.h — one (interval, instance) slot per thread: linearisation, elimination of the collocation point,
+// stage-QP assembly (k_eval) and expansion of the Riccati step (k_expand).
+#pragma once
+#include "layout.h"
+
+namespace ltompc {
+
+// ------------------------------------------------------------------------------------------ small dense LA
+__device__ __forceinline__ double sym_get(const double* H, int i, int j) { return H[sidx(i, j)]; }
+
+
+// Visits the inequalities of a slot in their storage order (input bounds, Radau-point bounds, node bounds; per
+// variable lower then upper, only the bounds that are set).  `f(m, kind, i, sg, val)` gets the running index m,
+// kind 0/1/2 = u / c / x+, and the variable index i as a value that is a compile-time constant after unrolling,
+// so that per-variable arrays stay in registers (a run-time index would force them into scratch memory).
+template <typename F>
+__device__ __forceinline__ int for_each_bound(const ltompc_params& p, F&& f) {
+  int m = 0;
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    if (p.u_lb[i] > -LTOMPC_NO_BOUND) f(m++, 0, i, -1.0, p.u_lb[i]);
+    if (p.u_ub[i] < LTOMPC_NO_BOUND) f(m++, 0, i, 1.0, p.u_ub[i]);
+  }
+#pragma unroll
+  for (int kind = 1; kind <= 2; kind++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      if (p.x_lb[i] > -LTOMPC_NO_BOUND) f(m++, kind, i, -1.0, p.x_lb[i]);
+      if (p.x_ub[i] < LTOMPC_NO_BOUND) f(m++, kind, i, 1.0, p.x_ub[i]);
+    }
+  }
+  return m;  // index of the first track constraint
+}
+
+// ------------------------------------------------------------------------------------------ slot linearisation
+// Slot k owns (u_k, c_k, x_{k+1}) and the collocation equations of interval k in do_mpc's Radau-IIA(2) form
+//   G1 = h f(c,u) + 2 x_k - 1.5 c - 0.5 x+ = 0 ,  G2 = h f(x+,u) - 2 x_k + 4.5 c - 2.5 x+ = 0   
+struct Slot {
+  double xk[8], xp[8], c[8], u[2];
+  double E1[64], E2[64], G1[8], G2[8];
+  double Hc[36], gc0[8], gc1[8];     // QP block of c_k : gradient = gc0 + mu gc1 (barrier terms included)
+  double Hxp[36], gxp0[8], gxp1[8];  // QP block of x_{k+1}
+  double Du[2], gub0[2], gub1[2];    // input-bound barrier
+  double dcd[8], dxd[8], dud[2];     // parts of grad_z L that do not involve the collocation multipliers
+  double gcost[8];
+  double gs[3], gn[3], gm[3];        // gradients of gL, gR+, gR-
+  double gv[3];                      // values of gL, gR+, gR- at x_{k+1}
+  double rp_ineq, cmax, cmin, smult; // WITH_DUAL: max |h + t|, max / min t nu, sum |nu| over the slot's inequalities
+  double th_ineq, sumlog;            // WITH_DUAL: sum |h + t|, sum log t (filter measures of the current point)
+  double cost;
+  int m_nl;                          // storage index of gL
+  bool nl;
+};
+
+template <bool WITH_DUAL>
+__device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
+  const int N = W.N;
+  const double hdt = K.o.t_step;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    S.xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+    S.xp[i] = PL(W.X, i, k + 1, N + 1);
+    S.c[i] = PL(W.C, i, k, N);
+  }
+  S.u[0] = PL(W.U, 0, k, N), S.u[1] = PL(W.U, 1, k, N);
+  double l1[8], l2[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N);
+#pragma unroll
+  for (int i = 0; i < 36; i++) S.Hc[i] = 0.0, S.Hxp[i] = 0.0;
+  double f1[8], f2[8], J[48];
+  rhs_derivs(K.p, K.T, eps, S.c, f1, J, l1, hdt, S.Hc);
+#pragma unroll
+  for (int i = 0; i < 64; i++) S.E1[i] = 0.0, S.E2[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 48; i++) S.E1[i] = hdt * J[i];
+  rhs_derivs(K.p, K.T, eps, S.xp, f2, J, l2, hdt, S.Hxp);
+#pragma unroll
+  for (int i = 0; i < 48; i++) S.E2[i] = hdt * J[i];
+  f1[6] = f2[6] = S.u[0], f1[7] = f2[7] = S.u[1];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    S.E1[i * 8 + i] -= 1.5, S.E2[i * 8 + i] -= 2.5;
+    S.G1[i] = hdt * f1[i] + 2.0 * S.xk[i] - 1.5 * S.c[i] - 0.5 * S.xp[i];
+    S.G2[i] = hdt * f2[i] - 2.0 * S.xk[i] + 4.5 * S.c[i] - 2.5 * S.xp[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) S.gcost[i] = 0.0, S.gc0[i] = 0.0, S.gc1[i] = 0.0, S.gxp1[i] = 0.0, S.dcd[i] = 0.0;
+  S.cost = cost_eval(K.p, K.T, eps, S.xp, k == N - 1, S.gcost, S.Hxp);
+#pragma unroll
+  for (int i = 0; i < 8; i++) S.gxp0[i] = S.gcost[i], S.dxd[i] = S.gcost[i];
+  S.Du[0] = S.Du[1] = 0.0, S.gub0[0] = S.gub0[1] = 0.0, S.gub1[0] = S.gub1[1] = 0.0, S.dud[0] = S.dud[1] = 0.0;
+  // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
+  // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
+  double lprod = 1.0;  // sum of log t = log of products of 8 slacks (3 logarithms per slot, see d_linesearch)
+  const int m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
+    const double hv = sg * (xv - val);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    const double Sg = nu * it, g0 = sg * nu * (hv + t) * it, g1 = sg * it;
+    if (kind == 0) {
+      S.Du[j] += Sg, S.gub0[j] += g0, S.gub1[j] += g1;
+      if (WITH_DUAL) S.dud[j] += sg * nu;
+    } else if (kind == 1) {
+      S.Hc[sidx(j, j)] += Sg, S.gc0[j] += g0, S.gc1[j] += g1;
+      if (WITH_DUAL) S.dcd[j] += sg * nu;
+    } else {
+      S.Hxp[sidx(j, j)] += Sg, S.gxp0[j] += g0, S.gxp1[j] += g1;
+      if (WITH_DUAL) S.dxd[j] += sg * nu;
+    }
+    if (WITH_DUAL) {
+      S.rp_ineq = fmax(S.rp_ineq, fabs(hv + t));
+      S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+      S.th_ineq += fabs(hv + t), lprod *= t;
+      if ((m & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
+    }
+  });
+  S.m_nl = m_nl;
+  S.nl = (k + 1 <= N - 1);  // nl_cons are checked at nodes 1..N-1 (node 0 is data, node N is not checked)
+  if (S.nl) {
+    double hss[3], hmm[3];
+    cons_eval(K.p, K.T, eps, S.xp, S.gv, S.gs, S.gn, S.gm, hss, hmm);
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      int mm = m_nl + q;
+      double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N), it = 1.0 / t;
+      double Sg = nu * it, s0 = nu * (S.gv[q] + t) * it;
+      double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        S.gxp0[a] += s0 * g3[a], S.gxp1[a] += it * g3[a];
+        if (WITH_DUAL) S.dxd[a] += nu * g3[a];
+#pragma unroll
+        for (int c = 0; c <= a; c++) S.Hxp[sidx(a, c)] += Sg * g3[a] * g3[c];
+      }
+      S.Hxp[sidx(0, 0)] += nu * hss[q];
+      S.Hxp[sidx(2, 2)] += nu * hmm[q];
+      if (WITH_DUAL) {
+        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
+        S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
+        S.th_ineq += fabs(S.gv[q] + t), lprod *= t;
+        if ((mm & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3; q++) S.gv[q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
+  }
+  if (WITH_DUAL) S.sumlog += log(lprod);
+}
+
+// Elimination of the collocation point: with M8 = 4.5 I + 2 E2 E1,
+//   M8 dc = (2I - 4E2) dx - (I + 2E2) Bu du - G2 - 2 E2 G1 ,   dx+ = 2 (E1 dc + 2 dx + Bu du + G1)
+// Y = [Ac | Bc | bc] (8 x 11), AB = [A | B | b] (8 x 11).
+//
+// Structure.  With the states grouped a = (s, n, mu), b = (vx, vy, r), c = (delta, T): the kinematic rows of the
+// model do not depend on c, the dynamic rows do not depend on a, and the rows of c are d/dt = u.  Hence E1, E2 are
+// block UPPER triangular in (a, b, c) with E_ac = 0 and E_cc = -1.5 I / -2.5 I, so are M8 (with M_cc = 12 I), the
+// first 8 columns of Y and A (with A_cc = I): the elimination is two 3x3 inverses and block back-substitutions, and
+// every product below runs over the structurally non-zero range only (less than half of the dense flops).
+__host__ __device__ constexpr int gs_(int i) { return i < 3 ? 0 : (i < 6 ? 3 : 6); }  // first index of i's group
+__host__ __device__ constexpr int ge_(int i) { return i < 3 ? 2 : (i < 6 ? 5 : 7); }  // last index of i's group
+// row i of E1 / E2 is non-zero in columns elo_(i) .. ehi_(i)
+__host__ __device__ constexpr int elo_(int i) { return i < 6 ? gs_(i) : i; }
+__host__ __device__ constexpr int ehi_(int i) { return i < 3 ? 5 : (i < 6 ? 7 : i); }
+// column col of Y = [Ac | Bc | bc] is non-zero in rows 0 .. yrow_(col)
+__host__ __device__ constexpr int yrow_(int col) { return col < 8 ? ge_(col) : 7; }
+// Hessian of the Lagrangian of the collocation equations in c_k: second derivatives of the kinematic rows over
+// (s, n, mu, vx, vy), of the dynamic rows over (vx, vy, r, delta), and the diagonal barrier terms of the bounds
+__host__ __device__ constexpr bool hnz_(int i, int j) { return (i <= 4 && j <= 4) || (i >= 3 && i <= 6 && j >= 3 && j <= 6) || i == j; }
+__host__ __device__ constexpr int imin_(int x, int y) { return x < y ? x : y; }
+__host__ __device__ constexpr int imax_(int x, int y) { return x > y ? x : y; }
+
+struct M8Blocks {  // M8 = [[Maa Mab Mac], [0 Mbb Mbc], [0 0 12 I]]
+  double iaa[9], ibb[9];  // inverses of the diagonal blocks
+  double ab[9], ac[6], bc[6];
+};
+
+__device__ __forceinline__ bool inv33(const double* m, double* r) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const double id = 1.0 / det;
+  r[0] = c00 * id, r[1] = (m[2] * m[7] - m[1] * m[8]) * id, r[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  r[3] = c01 * id, r[4] = (m[0] * m[8] - m[2] * m[6]) * id, r[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  r[6] = c02 * id, r[7] = (m[1] * m[6] - m[0] * m[7]) * id, r[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  return fabs(det) > 1e-12;
+}
+
+// y = M8^-1 v for a right-hand side whose rows > RMAX are structurally zero (those of y are then zero too, not written)
+template <int RMAX>
+__device__ __forceinline__ void m8_solve(const M8Blocks& M, const double* v, double* y) {
+  double yc[2] = {0.0, 0.0}, yb[3] = {0.0, 0.0, 0.0};
+  if (RMAX >= 6) {
+    yc[0] = v[6] * (1.0 / 12.0), yc[1] = v[7] * (1.0 / 12.0);
+    y[6] = yc[0], y[7] = yc[1];
+  }
+  if (RMAX >= 3) {
+    double rb[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      rb[i] = v[3 + i];
+      if (RMAX >= 6) rb[i] -= M.bc[i * 2] * yc[0] + M.bc[i * 2 + 1] * yc[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) yb[i] = M.ibb[i * 3] * rb[0] + M.ibb[i * 3 + 1] * rb[1] + M.ibb[i * 3 + 2] * rb[2], y[3 + i] = yb[i];
+  }
+  double ra[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    ra[i] = v[i];
+    if (RMAX >= 3) ra[i] -= M.ab[i * 3] * yb[0] + M.ab[i * 3 + 1] * yb[1] + M.ab[i * 3 + 2] * yb[2];
+    if (RMAX >= 6) ra[i] -= M.ac[i * 2] * yc[0] + M.ac[i * 2 + 1] * yc[1];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) y[i] = M.iaa[i * 3] * ra[0] + M.iaa[i * 3 + 1] * ra[1] + M.iaa[i * 3 + 2] * ra[2];
+}
+// x = M8^-T v (dense v): forward substitution through the transposed blocks
+__device__ __forceinline__ void m8_solve_t(const M8Blocks& M, const double* v, double* x) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) x[i] = M.iaa[i] * v[0] + M.iaa[3 + i] * v[1] + M.iaa[6 + i] * v[2];
+  double rb[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) rb[i] = v[3 + i] - (M.ab[i] * x[0] + M.ab[3 + i] * x[1] + M.ab[6 + i] * x[2]);
+#pragma unroll
+  for (int i = 0; i < 3; i++) x[3 + i] = M.ibb[i] * rb[0] + M.ibb[3 + i] * rb[1] + M.ibb[6 + i] * rb[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double s = v[6 + i];
+#pragma unroll
+    for (int l = 0; l < 3; l++) s -= M.ac[l * 2 + i] * x[l] + M.bc[l * 2 + i] * x[3 + l];
+    x[6 + i] = s * (1.0 / 12.0);
+  }
+}
+
+template <int COL>
+__device__ __forceinline__ void condense_column(const Consts& K, const Slot& S, const M8Blocks& M, double* Y, double* AB) {
+  const double hdt = K.o.t_step;
+  constexpr int RM = yrow_(COL);
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (COL < 8) {
+#pragma unroll
+    for (int i = 0; i <= RM; i++) v[i] = ((i == COL) ? 2.0 : 0.0) - ((COL >= elo_(i) && COL <= ehi_(i)) ? 4.0 * S.E2[i * 8 + COL] : 0.0);
+  } else if (COL < 10) {
+    constexpr int j = 6 + COL - 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = -hdt * (((i == j) ? 1.0 : 0.0) + ((j >= elo_(i) && j <= ehi_(i)) ? 2.0 * S.E2[i * 8 + j] : 0.0));
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double s = -S.G2[i];
+#pragma unroll
+      for (int l = elo_(i); l <= ehi_(i); l++) s -= 2.0 * S.E2[i * 8 + l] * S.G1[l];
+      v[i] = s;
+    }
+  }
+  m8_solve<RM>(M, v, y);
+#pragma unroll
+  for (int i = 0; i <= RM; i++) Y[i * 11 + COL] = y[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s;
+    if (COL < 8) s = (i == COL) ? 2.0 : 0.0;
+    else if (COL < 10) s = (i == 6 + COL - 8) ? hdt : 0.0;
+    else s = S.G1[i];
+#pragma unroll
+    for (int l = elo_(i); l <= imin_(ehi_(i), RM); l++) s += S.E1[i * 8 + l] * y[l];
+    AB[i * 11 + COL] = 2.0 * s;
+  }
+}
+
+__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8Blocks& M, double* Y, double* AB) {
+  // M8(i, j) = 4.5 delta_ij + 2 sum_l E2(i, l) E1(l, j): l runs where row i of E2 and column j of E1 overlap
+  double maa[9], mbb[9];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = gs_(i); j < 8; j++) {
+      double s = (i == j) ? 4.5 : 0.0;
+#pragma unroll
+      for (int l = elo_(i); l <= imin_(ehi_(i), ge_(j)); l++)
+        if (j >= elo_(l) && j <= ehi_(l)) s += 2.0 * S.E2[i * 8 + l] * S.E1[l * 8 + j];
+      if (i < 3) {
+        if (j < 3) maa[i * 3 + j] = s;
+        else if (j < 6) M.ab[i * 3 + j - 3] = s;
+        else M.ac[i * 2 + j - 6] = s;
+      } else {
+        if (j < 6) mbb[(i - 3) * 3 + j - 3] = s;
+        else M.bc[(i - 3) * 2 + j - 6] = s;
+      }
+    }
+  const bool ok = inv33(maa, M.iaa) & inv33(mbb, M.ibb);
+#pragma unroll
+  for (int q = 0; q < 88; q++) Y[q] = 0.0, AB[q] = 0.0;
+  condense_column<0>(K, S, M, Y, AB), condense_column<1>(K, S, M, Y, AB), condense_column<2>(K, S, M, Y, AB);
+  condense_column<3>(K, S, M, Y, AB), condense_column<4>(K, S, M, Y, AB), condense_column<5>(K, S, M, Y, AB);
+  condense_column<6>(K, S, M, Y, AB), condense_column<7>(K, S, M, Y, AB), condense_column<8>(K, S, M, Y, AB);
+  condense_column<9>(K, S, M, Y, AB), condense_column<10>(K, S, M, Y, AB);
+  return ok;
+}
+
+
+// ------------------------------------------------------------------------------------------ k_eval
+__device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b) {
+  const int N = W.N;
+  if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  if (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b]) return;  // blocks of the last launch are still valid
+  const double hdt = K.o.t_step;
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  Slot S;
+  linearise_slot<true>(K, W, k, b, eps, S);
+  // ---- residual partials (IPOPT's E_mu ingredients) ----
+  {
+    double l1[8], l2[8], rd = 0.0, rp = 0.0, sm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N);
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+      double rcx = S.dcd[a] + 4.5 * l2[a];
+      double rxp = S.dxd[a] - 0.5 * l1[a];
+#pragma unroll
+      for (int i = 0; i <= ge_(a); i++)  // column a of E1 / E2: rows of the groups up to a's
+        if (a >= elo_(i) && a <= ehi_(i)) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
+      if (k + 1 < N) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);
+      rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
+      rp = fmax(rp, fmax(fabs(S.G1[a]), fabs(S.G2[a])));
+      sm += fabs(l1[a]) + fabs(l2[a]);
+    }
+    double cost = S.cost;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double v = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+      double du = S.u[i] - v;
+      cost += K.p.r_du[i] * du * du;
+      double ru = S.dud[i] + 2.0 * K.p.r_du[i] * du + hdt * (l1[6 + i] + l2[6 + i]);
+      if (k + 1 < N) ru -= 2.0 * K.p.r_du[i] * (PL(W.U, i, k + 1, N) - S.u[i]);
+      rd = fmax(rd, fabs(ru));
+    }
+    rp = fmax(rp, S.rp_ineq), sm += S.smult;
+    const double cmax = S.cmax, cmin = S.cmin;
+    // filter measures of the current point (candidate 0 of the line search) come for free here
+    double th0 = S.th_ineq;
+#pragma unroll
+    for (int a = 0; a < 8; a++) th0 += fabs(S.G1[a]) + fabs(S.G2[a]);
+    PL(W.LS, 0, k, N) = th0, PL(W.LS, 1, k, N) = cost, PL(W.LS, 2, k, N) = S.sumlog;
+    PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
+    PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
+  }
+  // ---- eliminate the collocation point, project its QP block onto (x_k, u_k) ----
+  M8Blocks M8;
+  double Y[88], AB[88];
+  condense_slot(K, S, M8, Y, AB);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) PG(W.QP, QP_A + i * 8 + j, k, QP_NF) = AB[i * 11 + j];
+    PG(W.QP, QP_B + i * 2 + 0, k, QP_NF) = AB[i * 11 + 8], PG(W.QP, QP_B + i * 2 + 1, k, QP_NF) = AB[i * 11 + 9];
+    PG(W.QP, QP_b + i, k, QP_NF) = AB[i * 11 + 10];
+  }
+  double HY[88];  // Hc * [Ac | Bc | bc]; column col of Y is non-zero in rows 0 .. yrow_(col)
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+#pragma unroll
+    for (int col = 0; col < 11; col++) {
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l <= yrow_(col); l++)
+        if (hnz_(i, l)) s += sym_get(S.Hc, i, l) * Y[l * 11 + col];
+      HY[i * 11 + col] = s;
+    }
+  // Q = Ac^T Hc Ac, S = Bc^T Hc Ac, R = Bc^T Hc Bc + Du; q = [Ac|Bc]^T (Hc bc + gc0 + mu gc1) (+ gub)
+#pragma unroll
+  for (int i = 0; i < 10; i++) {
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+      if (j > i) continue;
+      double s = 0.0;
+#pragma unroll
+      for (int l = 0; l <= yrow_(i); l++) s += Y[l * 11 + i] * HY[l * 11 + j];
+      if (i < 8) PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) = s;
+      else if (j < 8) PG(W.QP, QP_S + (i - 8) * 8 + j, k, QP_NF) = s;
+      else PG(W.QP, QP_R + sidx(i - 8, j - 8), k, QP_NF) = s + ((i == j) ? S.Du[i - 8] : 0.0);
+    }
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int l = 0; l <= yrow_(i); l++) s0 += Y[l * 11 + i] * (HY[l * 11 + 10] + S.gc0[l]), s1 += Y[l * 11 + i] * S.gc1[l];
+    if (i < 8) PG(W.QP, QP_q0 + i, k, QP_NF) = s0, PG(W.QP, QP_q1 + i, k, QP_NF) = s1;
+    else PG(W.QP, QP_r0 + i - 8, k, QP_NF) = s0 + S.gub0[i - 8], PG(W.QP, QP_r1 + i - 8, k, QP_NF) = s1 + S.gub1[i - 8];
+  }
+#pragma unroll
+  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k + 1, QP_NF) = S.Hxp[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
+}
+
+__global__ void __launch_bounds__(64) k_eval(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_eval(K, W, k, la.act[j]);
+}
+
+
+// ------------------------------------------------------------------------------------------ k_expand
+__device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const int k, const int b) {
+  const int N = W.N;
+  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
+  const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
+  Slot S;
+  linearise_slot<false>(K, W, k, b, eps, S);
+  M8Blocks M8;
+  double Y[88], AB[88];
+  condense_slot(K, S, M8, Y, AB);
+  double dxk[8], dxp[8], du[2], dc[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) dxk[i] = PL(W.dX, i, k, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+  du[0] = PL(W.dU, 0, k, N), du[1] = PL(W.dU, 1, k, N);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = Y[i * 11 + 10] + Y[i * 11 + 8] * du[0] + Y[i * 11 + 9] * du[1];
+#pragma unroll
+    for (int j = gs_(i); j < 8; j++)  // row i of Ac: block upper triangular, its (delta, T) block is the identity
+      if (i < 6 || j == i) s += Y[i * 11 + j] * dxk[j];
+    dc[i] = s;
+    PL(W.dC, i, k, N) = s;
+  }
+  // costate pi_{k+1} = P_{k+1} dx_{k+1} + Pxv_{k+1} du_k + p_{k+1}
+  double pi[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = PG(W.RC, RC_pp + i, k + 1, RC_NF) + PG(W.RC, RC_Pxv + i * 2, k + 1, RC_NF) * du[0] +
+               PG(W.RC, RC_Pxv + i * 2 + 1, k + 1, RC_NF) * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += PG(W.RC, RC_P + sidx(i, j), k + 1, RC_NF) * dxp[j];
+    pi[i] = s;
+  }
+  // new collocation multipliers:  M8^T l2 = -(Hc dc + gc) - 2 E1^T pi ;  l1 = 2 (E2^T l2 + pi)
+  double v[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = S.gc0[i] + mu * S.gc1[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (hnz_(i, j)) s += sym_get(S.Hc, i, j) * dc[j];
+      if (i >= elo_(j) && i <= ehi_(j)) s += 2.0 * S.E1[j * 8 + i] * pi[j];
+    }
+    v[i] = -s;
+  }
+  {
+    double l2[8];
+    m8_solve_t(M8, v, l2);
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = l2[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    double s = pi[i];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (i >= elo_(j) && i <= ehi_(j)) s += S.E2[j * 8 + i] * v[j];
+    PL(W.nL1, i, k, N) = 2.0 * s;
+    PL(W.nL2, i, k, N) = v[i];
+  }
+  // slack / multiplier steps, fraction to the boundary, directional derivative of the barrier objective
+  double r_pri = 0.0, a_dua = 1.0, gphid = 0.0;  // r_pri = max(-dt / t) over the slot's inequalities
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    double v0 = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+    double dv0 = k ? PL(W.dU, i, k - 1, N) : 0.0;
+    gphid += 2.0 * K.p.r_du[i] * (S.u[i] - v0) * (du[i] - dv0);
+  }
+#pragma unroll
+  for (int a = 0; a < 8; a++) gphid += S.gcost[a] * dxp[a];
+  // (one flat visitor: an earlier version with a second, nested by-reference lambda produced run-to-run varying
+  //  values of gphid for the last interval on ROCm 7.2 / gfx950, a code-generation problem that instrumenting stores
+  //  made disappear; tests/test_gpu_parity.py::test_full_size_batch_properties guards against its return)
+  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
+    const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
+    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    const double dtt = -(sg * (xv - val) + t) - sg * dv;
+    const double dn = (mu - nu * dtt) * it - nu;
+    PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+    r_pri = fmax(r_pri, -dtt * it);  // fraction to the boundary: alpha <= tau t / (-dt) for dt < 0, i.e. tau / max(-dt / t)
+    if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+    gphid -= mu * dtt * it;
+  });
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int m = S.m_nl + q;
+    if (S.nl) {
+      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+      const double dtt = -(S.gv[q] + t) - (S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
+      const double dn = (mu - nu * dtt) * it - nu;
+      PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+      r_pri = fmax(r_pri, -dtt * it);
+      if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+      gphid -= mu * dtt * it;
+    } else {
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+    }
+  }
+  const double a_pri = r_pri > tau ? tau / r_pri : 1.0;
+  PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
+}
+
+__global__ void __launch_bounds__(64) k_expand(Consts K, Work W, Launch la) {
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_expand(K, W, k, la.act[j]);
+}
+
+}  // namespace ltompc

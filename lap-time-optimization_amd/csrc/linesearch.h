@@ -1,0 +1,297 @@
+// linesearch.h — step candidates, filter test, update (k_linesearch, k_pick, k_update) and their fusion for narrow
+// launches (k_step1).
+#pragma once
+#include "layout.h"
+
+namespace ltompc {
+
+// ------------------------------------------------------------------------------------------ k_linesearch
+// candidate 0 is the current point (alpha = 0); candidate l >= 1 has alpha = a_pri * 2^-(l-1).
+// LS plane layout: [3 * (n_ls + 1)][N][Bp] : theta, cost, sum log t per candidate.
+// Two phases (97% of all iterations accept the full step): phase 0 evaluates the current point and the first candidate
+// for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
+// Filter measures (theta, cost, sum log t) of the step candidates l_begin..l_end of interval k of instance b;
+// candidate l >= 1 has alpha = a_pri * 2^-(l-1) (l = 0, the current point, is written by k_eval).
+__device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, const int k, const int b, const int l_begin,
+                                             const int l_end) {
+  const int N = W.N;
+  const double hdt = K.o.t_step;
+  if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  double a_pri = 1.0;
+  for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
+  double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
+    dxk[i] = PL(W.dX, i, k, N + 1);
+    xp[i] = PL(W.X, i, k + 1, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
+    c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    u[i] = PL(W.U, i, k, N), du[i] = PL(W.dU, i, k, N);
+    v[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+    dv[i] = k ? PL(W.dU, i, k - 1, N) : 0.0;
+  }
+  const bool nl = (k + 1 <= N - 1);
+  // candidate index l: 0 = current point, l >= 1: alpha = a_pri * 2^-(l-1)
+  for (int l = l_begin; l <= l_end; l++) {
+    const double alpha = l == 0 ? 0.0 : ldexp(a_pri, -(l - 1));
+    double txk[8], txp[8], tc[8], tu[2], tv[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) txk[i] = xk[i] + alpha * dxk[i], txp[i] = xp[i] + alpha * dxp[i], tc[i] = c[i] + alpha * dc[i];
+#pragma unroll
+    for (int i = 0; i < 2; i++) tu[i] = u[i] + alpha * du[i], tv[i] = v[i] + alpha * dv[i];
+    double f1[8], f2[8];
+    rhs_val(K.p, K.T, eps, tc, tu, f1);
+    rhs_val(K.p, K.T, eps, txp, tu, f2);
+    double th = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      th += fabs(hdt * f1[i] + 2.0 * txk[i] - 1.5 * tc[i] - 0.5 * txp[i]);
+      th += fabs(hdt * f2[i] - 2.0 * txk[i] + 4.5 * tc[i] - 2.5 * txp[i]);
+    }
+    double co = cost_eval(K.p, K.T, eps, txp, k == N - 1, nullptr, nullptr);
+#pragma unroll
+    for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
+    // sum of log t as the log of products of 8 slacks (same grouping in linearise_slot): 3 logarithms instead of 23
+    double sl = 0.0, pr = 1.0;
+    const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
+      const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
+      const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+      th += fabs(sg * (xv - val) + t), pr *= t;
+      if ((mm & 7) == 7) sl += log(pr), pr = 1.0;
+    });
+    if (nl) {
+      double gv[3];
+      cons_eval(K.p, K.T, eps, txp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
+        th += fabs(gv[q] + t), pr *= t;
+        if (((m + q) & 7) == 7) sl += log(pr), pr = 1.0;
+      }
+    }
+    sl += log(pr);
+    PL(W.LS, 3 * l + 0, k, N) = th, PL(W.LS, 3 * l + 1, k, N) = co, PL(W.LS, 3 * l + 2, k, N) = sl;
+  }
+}
+
+__global__ void __launch_bounds__(64, 2) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
+  // phase 1: thread = (candidate, k, j'), one candidate each (latency matters here, not throughput), over the packed
+  //          list of rejected instances; jw = launch width in instances, longer lists are covered grid-stride.
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = W.N;
+  const int j0 = tid % jw, rest = tid / jw, k = rest % N, cand = rest / N;
+  if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
+  const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
+  const int l = phase == 0 ? 1 : 2 + cand;
+  for (int j = j0; j < count; j += jw) d_linesearch(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
+}
+
+// ------------------------------------------------------------------------------------------ k_pick
+// Filter line search of Waechter & Biegler 2006 (no second-order correction, no restoration phase).
+// 8 lanes per instance (lane = g + 8 i, all 8 lanes of a group call this together): lane i reduces the stage partials
+// k = i, i+8, ...; the 8 lanes then hold the same numbers and take the same decisions, lane i == 0 writes.  (Keeps the
+// latency of this small step at N/8 dependent loads instead of N.)
+__device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int b, const int i, const int phase,
+                                       const bool append_list) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  if (STI(SI_DONE) || !STI(SI_STEP)) return;  // finished, or the Riccati sweep of this launch has to be repeated
+  const ltompc_options& o = K.o;
+  const double mu = STD(ST_MU);
+  double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
+  for (int k = i; k < N; k += 8) {
+    a_pri = fmin(a_pri, PL(W.SP, SP_apri, k, N)), a_dua = fmin(a_dua, PL(W.SP, SP_adua, k, N));
+    gphid += PL(W.SP, SP_gphid, k, N);
+  }
+  a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
+  // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
+  const double c00 = STD(ST_C00);
+  auto measures = [&](int l, double& th, double& ph) {
+    double t = 0.0, c = 0.0, s = 0.0;
+    for (int k = i; k < N; k += 8) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
+    t = grp_sum(t), c = grp_sum(c), s = grp_sum(s);
+    th = t, ph = (c00 + c) - mu * s;
+  };
+  double th0, ph0;
+  measures(0, th0, ph0);
+  double theta0 = STD(ST_THETA0);
+  int nfilt = STI(SI_NFILT);
+  double theta_max = STD(ST_THMAX), theta_min = STD(ST_THMIN);
+  if (theta0 < 0.0) {
+    theta0 = th0, theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
+    if (i == 0) STD(ST_THETA0) = theta0, STD(ST_THMAX) = theta_max, STD(ST_THMIN) = theta_min;
+    nfilt = 0;
+  }
+  const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0;
+  bool accepted = false;
+  double alpha = a_pri;
+  const int n_ls = o.n_linesearch;
+  const int n_try = (phase == 0) ? 1 : n_ls;  // phase 1 repeats the test of candidate 0 (same outcome) and goes on
+  for (int l = 0; l < n_try; l++, alpha *= 0.5) {
+    double th, ph;
+    measures(l + 1, th, ph);
+    if (!isfinite(th) || !isfinite(ph) || th > theta_max) continue;
+    bool in_filter = false;
+    for (int f = 0; f < nfilt; f++)
+      if (th >= W.filt[(size_t)(2 * f) * W.Bp + b] && ph >= W.filt[(size_t)(2 * f + 1) * W.Bp + b]) {
+        in_filter = true;
+        break;
+      }
+    if (in_filter) continue;
+    bool sw = (gphid < 0.0) && (alpha * pow(-gphid, s_ph) > dlt * pow(th0, s_th));
+    bool armijo = ph <= ph0 + eta_ph * alpha * gphid;
+    bool ok;
+    if (th0 <= theta_min && sw) ok = armijo;
+    else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
+    if (!ok) continue;
+    if (!(sw && armijo)) {  // augment the filter (written by lane i == 0, nobody reads it again in this launch)
+      if (nfilt == FILTER_MAX) {
+        if (i == 0)
+          for (int f = 0; f + 1 < FILTER_MAX; f++) {
+            W.filt[(size_t)(2 * f) * W.Bp + b] = W.filt[(size_t)(2 * f + 2) * W.Bp + b];
+            W.filt[(size_t)(2 * f + 1) * W.Bp + b] = W.filt[(size_t)(2 * f + 3) * W.Bp + b];
+          }
+        nfilt--;
+      }
+      if (i == 0) {
+        W.filt[(size_t)(2 * nfilt) * W.Bp + b] = (1.0 - g_th) * th0;
+        W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * th0;
+      }
+      nfilt++;
+    }
+    accepted = true;
+    break;
+  }
+  if (i != 0) return;  // one writer per instance from here on
+  if (phase == 0) {
+    STI(SI_LSMORE) = (!accepted && n_ls > 1) ? 1 : 0;
+    if (!accepted && n_ls > 1) {  // nothing has been modified yet: phase 1 decides
+      if (append_list) W.ls_list[atomicAdd(W.ls_count, 1)] = b;
+      return;
+    }
+  } else {
+    STI(SI_LSMORE) = 0;
+  }
+  bool take = true, give_up = false;
+  if (!accepted) {
+    const int nf = STI(SI_NLSFAIL) + 1;
+    STI(SI_NLSFAIL) = nf;
+    double fr = STD(ST_FORCE_REG);
+    if (o.max_ls_fail > 0 && nf >= o.max_ls_fail) {
+      give_up = true, take = false;
+    } else if (fr < 1e4) {
+      STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 : fr * 100.0;
+      take = false;
+    } else {
+      nfilt = 0;
+      alpha = a_pri * pow(0.5, (double)(n_ls - 1));
+    }
+  }
+  if (give_up) STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+  if (take) {
+    STD(ST_FORCE_REG) = 0.0;
+    int nt = alpha <= 1e-3 ? STI(SI_NTINY) + 1 : 0;
+    STI(SI_NTINY) = nt;
+    if (o.stall_iter > 0 && nt >= o.stall_iter) {
+      STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+      take = false;
+    }
+  }
+  STD(ST_ALPHA) = take ? alpha : 0.0, STD(ST_ADUA) = a_dua;
+  STI(SI_STEP) = take ? 1 : 0;
+  if (!STI(SI_DONE)) STI(SI_ITERS) += 1;  // (a solve that stops here has completed `iters` iterations, like the oracle)
+  // table smoothing follows the barrier parameter with one iteration lag; the filter restarts when it changes
+  bool eps_switched = false;
+  if (STD(ST_EPS_NEXT) != STD(ST_EPS)) {
+    STD(ST_EPS) = STD(ST_EPS_NEXT);
+    {
+      double x0[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) x0[q] = W.x0[(size_t)q * W.Bp + b];
+      STD(ST_C00) = cost_eval(K.p, K.T, STD(ST_EPS_NEXT), x0, false, nullptr, nullptr);
+    }
+    nfilt = 0, STD(ST_THETA0) = -1.0;
+    eps_switched = true;
+  }
+  STI(SI_NFILT) = nfilt;
+  STI(SI_SKIP_EVAL) = (!take && !eps_switched) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
+}
+
+__global__ void __launch_bounds__(64) k_pick(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int j = blockIdx.x * 8 + g;
+  if (j >= (phase == 0 ? la.nact[0] : W.ls_count[0])) return;
+  d_pick(K, W, phase == 0 ? la.act[j] : W.ls_list[j], i, phase, true);
+}
+
+// ------------------------------------------------------------------------------------------ k_update
+__device__ __forceinline__ void d_update(const Consts& K, const Work& W, const int k, const int b) {
+  const int N = W.N;
+  if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
+  const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
+  const double mu = W.st[(size_t)ST_MU * W.Bp + b];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    PL(W.X, i, k + 1, N + 1) += alpha * PL(W.dX, i, k + 1, N + 1);
+    PL(W.C, i, k, N) += alpha * PL(W.dC, i, k, N);
+    double l1 = PL(W.L1, i, k, N), l2 = PL(W.L2, i, k, N);
+    PL(W.L1, i, k, N) = l1 + alpha * (PL(W.nL1, i, k, N) - l1);
+    PL(W.L2, i, k, N) = l2 + alpha * (PL(W.nL2, i, k, N) - l2);
+  }
+  PL(W.U, 0, k, N) += alpha * PL(W.dU, 0, k, N), PL(W.U, 1, k, N) += alpha * PL(W.dU, 1, k, N);
+  const int ni = K.bd.ni, nact = (k + 1 <= N - 1) ? ni : ni - 3;
+  for (int m = 0; m < nact; m++) {
+    double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
+    double nu = PL(W.NU, m, k, N) + a_dua * PL(W.dNU, m, k, N);
+    double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
+    PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
+  }
+}
+
+__global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
+  int j = tid % la.n_pad, k = tid / la.n_pad;
+  if (k >= W.N || j >= la.nact[0]) return;
+  d_update(K, W, k, la.act[j]);
+}
+
+
+// ------------------------------------------------------------------------------------------ k_step1
+// Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
+// and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
+__global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {  // 320 = 8 candidates x 40 intervals in one pass
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  if ((int)blockIdx.x >= la.nact[0]) return;
+  const int b = la.act[blockIdx.x];
+  const int N = W.N, tid = threadIdx.x;
+  const int* si = W.si;
+  if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
+  // all step candidates at once (the threads are there anyway; the wide path evaluates candidates 2.. only for the
+  // instances that rejected the full step, with the same arithmetic)
+  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
+  __syncthreads();
+  if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
+  __syncthreads();
+  if (si[(size_t)SI_LSMORE * W.Bp + b]) {  // block-uniform (written before the barrier)
+    if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
+    __syncthreads();
+  }
+  for (int kk = tid; kk < N; kk += 320) d_update(K, W, kk, b);
+}
+
+
+}  // namespace ltompc

@@ -12,7 +12,6 @@
 #include <vector>
 
 #include "kernels.h"
-#include "eval8.h"
 
 using namespace ltompc;
 

@@ -1,0 +1,995 @@
+// riccati.h — termination test, barrier update and the Riccati sweep: one thread per instance (k_riccati, reference
+// implementation), 8 instances per wavefront (k_riccati8), one instance per wavefront (k_riccati1).
+#pragma once
+#include "layout.h"
+
+namespace ltompc {
+
+// ------------------------------------------------------------------------------------------ k_riccati
+// One thread per instance.  State of the recursion is (x_k, v_k = u_{k-1}) because do_mpc's rterm penalises
+// u_k - u_{k-1} (controller.py:40-41): stage cost r |u_k - v_k|^2, v_{k+1} = u_k.
+__global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int it_index) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= la.nact[0]) return;
+  const int b = la.act[j];
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  if (STI(SI_DONE)) return;
+  const ltompc_options& o = K.o;
+  // ---- reduce residual partials, KKT error, termination (IPOPT eq. (5),(6)) ----
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, smult = 0.0;
+  double obj;
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
+  for (int k = 0; k < N; k++) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+    smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  }
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;  // multipliers counted (last slot has no nl constraints)
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+  int iters = STI(SI_ITERS);
+  int term = -1;
+  if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+  else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+  else {
+    if (E0 <= o.acceptable_tol) {
+      int na = STI(SI_NACC) + 1;
+      STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE;
+    } else STI(SI_NACC) = 0;
+    if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+  }
+  if (term >= 0) {
+    STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+    return;
+  }
+  atomicAdd(&W.active[it_index], 1);
+  // ---- monotone barrier update (IPOPT eq. (7)) ----
+  bool mu_changed = false;
+  while (Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (mu_changed) {
+    STD(ST_MU) = mu;
+    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+    STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+  }
+  STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  // ---- backward sweep, retried with Hessian regularisation until every Huu is positive definite ----
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  int tries = 0;
+  bool numerical = false;
+  for (;;) {
+    bool ok = true;
+    double P[64], Pxv[16], Pvv[4], pp[8], pv[2];
+    // terminal node block (slot N-1)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) P[i * 8 + j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);
+      pp[i] = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
+      Pxv[i * 2] = Pxv[i * 2 + 1] = 0.0;
+    }
+    Pvv[0] = Pvv[1] = Pvv[2] = Pvv[3] = 0.0, pv[0] = pv[1] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = P[i * 8 + j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = pp[i];
+    }
+    for (int k = N - 1; k >= 0; k--) {
+      double A[64], Bm[16], bv[8];
+#pragma unroll
+      for (int i = 0; i < 64; i++) A[i] = PG(W.QP, QP_A + i, k, QP_NF);
+#pragma unroll
+      for (int i = 0; i < 16; i++) Bm[i] = PG(W.QP, QP_B + i, k, QP_NF);
+#pragma unroll
+      for (int i = 0; i < 8; i++) bv[i] = PG(W.QP, QP_b + i, k, QP_NF);
+      double PA[64], PB[16], Pb[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += P[i * 8 + l] * A[l * 8 + j];
+          PA[i * 8 + j] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += P[i * 8 + l] * Bm[l * 2 + j];
+          PB[i * 2 + j] = s;
+        }
+        double s = pp[i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += P[i * 8 + l] * bv[l];
+        Pb[i] = s;
+      }
+      double Huu[4], Hux[16], gu[2], uk[2], vk[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        uk[i] = PL(W.U, i, k, N);
+        vk[i] = k ? PL(W.U, i, k - 1, N) : W.uprev[(size_t)i * W.Bp + b];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          double s = PG(W.QP, QP_R + sidx(i, j), k, QP_NF) + Pvv[i * 2 + j];
+#pragma unroll
+          for (int l = 0; l < 8; l++)
+            s += Bm[l * 2 + i] * PB[l * 2 + j] + Bm[l * 2 + i] * Pxv[l * 2 + j] + Pxv[l * 2 + i] * Bm[l * 2 + j];
+          Huu[i * 2 + j] = s;
+        }
+        Huu[i * 2 + i] += r2[i] + delta_w;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = PG(W.QP, QP_S + i * 8 + j, k, QP_NF);
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * PA[l * 8 + j] + Pxv[l * 2 + i] * A[l * 8 + j];
+          Hux[i * 8 + j] = s;
+        }
+        double s = PG(W.QP, QP_r0 + i, k, QP_NF) + mu * PG(W.QP, QP_r1 + i, k, QP_NF) + r2[i] * (uk[i] - vk[i]) + pv[i];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += Bm[l * 2 + i] * Pb[l] + Pxv[l * 2 + i] * bv[l];
+        gu[i] = s;
+      }
+      double Hxx[64], gx[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          double s = PG(W.QP, QP_Q + sidx(i, j), k, QP_NF) + ((i == j) ? delta_w : 0.0);
+          if (k > 0) s += PG(W.QP, QP_Qx + sidx(i, j), k, QP_NF);
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += A[l * 8 + i] * PA[l * 8 + j];
+          Hxx[i * 8 + j] = s;
+        }
+        double s = PG(W.QP, QP_q0 + i, k, QP_NF) + mu * PG(W.QP, QP_q1 + i, k, QP_NF);
+        if (k > 0) s += PG(W.QP, QP_qx0 + i, k, QP_NF) + mu * PG(W.QP, QP_qx1 + i, k, QP_NF);
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += A[l * 8 + i] * Pb[l];
+        gx[i] = s;
+      }
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      if (!(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det)) {
+        ok = false;
+        break;
+      }
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kx[16], Kv[4], kff[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) Kx[i * 8 + j] = -(Hi[i * 2 + 0] * Hux[0 * 8 + j] + Hi[i * 2 + 1] * Hux[1 * 8 + j]);
+#pragma unroll
+        for (int j = 0; j < 2; j++) Kv[i * 2 + j] = Hi[i * 2 + j] * r2[j];
+        kff[i] = -(Hi[i * 2 + 0] * gu[0] + Hi[i * 2 + 1] * gu[1]);
+      }
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) P[i * 8 + j] = Hxx[i * 8 + j] + Hux[0 * 8 + i] * Kx[0 * 8 + j] + Hux[1 * 8 + i] * Kx[1 * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 2; j++) Pxv[i * 2 + j] = Hux[0 * 8 + i] * Kv[0 * 2 + j] + Hux[1 * 8 + i] * Kv[1 * 2 + j];
+        pp[i] = gx[i] + Hux[0 * 8 + i] * kff[0] + Hux[1 * 8 + i] * kff[1];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) Pvv[i * 2 + j] = ((i == j) ? r2[i] : 0.0) - r2[i] * Kv[i * 2 + j];
+        pv[i] = gv[i] - r2[i] * kff[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < i; j++) {
+          double s = 0.5 * (P[i * 8 + j] + P[j * 8 + i]);
+          P[i * 8 + j] = s, P[j * 8 + i] = s;
+        }
+#pragma unroll
+      for (int i = 0; i < 16; i++) PG(W.RC, RC_K + i, k, RC_NF) = Kx[i];
+#pragma unroll
+      for (int i = 0; i < 4; i++) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+      PG(W.RC, RC_kff + 0, k, RC_NF) = kff[0], PG(W.RC, RC_kff + 1, k, RC_NF) = kff[1];
+      if (k > 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+          for (int j = 0; j <= i; j++) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = P[i * 8 + j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = Pxv[i * 2], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = Pxv[i * 2 + 1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = pp[i];
+        }
+      }
+    }
+    if (ok) break;
+    // inertia correction schedule (Waechter & Biegler 2006, Algorithm IC)
+    if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+    else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+    STI(SI_NREG) += 1;
+    if (++tries > 40 || delta_w > 1e20) {
+      numerical = true;
+      break;
+    }
+  }
+  if (numerical) {
+    STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+    return;
+  }
+  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+  else if (dw_last <= DW_KEEP) STD(ST_DW_LAST) = 0.0;
+  STD(ST_DW) = delta_w;
+  // ---- forward rollout ----
+  double dx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[2] = {0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; i++) PL(W.dX, i, 0, N + 1) = 0.0;
+  for (int k = 0; k < N; k++) {
+    double du[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      double s = PG(W.RC, RC_kff + i, k, RC_NF) + PG(W.RC, RC_Kv + i * 2, k, RC_NF) * dv[0] + PG(W.RC, RC_Kv + i * 2 + 1, k, RC_NF) * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += PG(W.RC, RC_K + i * 8 + j, k, RC_NF) * dx[j];
+      du[i] = s;
+    }
+    double dn[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double s = PG(W.QP, QP_b + i, k, QP_NF) + PG(W.QP, QP_B + i * 2, k, QP_NF) * du[0] + PG(W.QP, QP_B + i * 2 + 1, k, QP_NF) * du[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += PG(W.QP, QP_A + i * 8 + j, k, QP_NF) * dx[j];
+      dn[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) dx[i] = dn[i], PL(W.dX, i, k + 1, N + 1) = dn[i];
+    dv[0] = du[0], dv[1] = du[1];
+    PL(W.dU, 0, k, N) = du[0], PL(W.dU, 1, k, N) = du[1];
+  }
+  STI(SI_STEP) = 1;
+}
+
+// ------------------------------------------------------------------------------------------ k_riccati8
+// Wave-cooperative form of k_riccati: a wavefront = 8 instances x 8 lanes, lane (g, i) = (lane & 7, lane >> 3)
+// owns ROW i of the 8x8 blocks of instance b = 8 * blockIdx.x + g.  With the instance index fastest in HBM the
+// 8 lanes that read one field of 8 neighbouring instances fetch one full 64-byte sector.  Stage blocks A, B, b
+// and the row-exchanged products (P A, P B, P b + p, K, P) live in LDS as [field][g] (conflict-free: a
+// wave-wide ds_read_b64 touches 8 or 64 consecutive doubles).  Same arithmetic as k_riccati.
+struct RicLds {
+  // The stage blocks of the wavefront's 8 instances, double-buffered, as [field][g] (the layout of the QP buffer, so the
+  // A, B, b the products need are read in place): lane (g, i) fetches fields i, i + 8, ... of instance g one stage
+  // ahead (27 loads per lane instead of the 45 values a lane needs itself, and no second register set for them).
+  double sb[2][(QP_NF + 1) * 8];  // 27 x 8 fields: lane row 7 fetches one field past the block (padding, never read)
+  double PA[64][8], PB[16][8], Pb[8][8], K[16][8], Pxv[16][8];  // (the new P is exchanged through PA: P A is dead by then)
+};  // 35.2 kB: four wavefronts per CU
+
+
+// In a one-wavefront workgroup LDS instructions execute in program order, so exchanging data through LDS needs
+
+struct FwdRegs {
+  double K[16], Kv[4], kff[2], A[8], B[2], b;
+};
+
+// All 64 lanes of a wavefront call this together; lane (g, i) works on row i of instance b (padding lanes: valid =
+// false, they shadow a real instance read-only).  active_slot >= 0: count the unfinished instances there.
+__device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLds& L, const int g, const int i, const int b,
+                                           const bool valid, const int active_slot, const int max_sweeps) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  const ltompc_options& o = K.o;
+  bool live = valid && !STI(SI_DONE);
+  if (!__any(live)) return;
+  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
+  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
+  // than one sweep however hard the worst instance of the batch is.
+  const bool retry = live && STI(SI_RETRY);
+  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
+  //      every lane (identical to the serial kernel, so that both produce the same bits)
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
+  for (int k = i; k < N; k += 8) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+  }
+  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
+  double smult = 0.0, obj;
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
+  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  int term = -1;
+  if (live && !retry) {
+    int iters = STI(SI_ITERS);
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
+      if (i == 0) STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (i == 0) {
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+    }
+    if (term >= 0) live = false;
+  }
+  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
+  if (!__any(live)) return;
+  // ---- monotone barrier update
+  bool mu_changed = false;
+  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (live && !retry && i == 0) {
+    if (mu_changed) {
+      STD(ST_MU) = mu;
+      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+    }
+    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  }
+  // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
+  //      the others recompute the same numbers)
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  int tries = 0;
+  if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
+  bool numerical = false;
+  // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
+  // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
+  // once only the stragglers are left
+  constexpr int NPF = (QP_NF + 7) / 8;  // fields a lane fetches per stage block
+  const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
+  for (int sweep = 0;; sweep++) {
+    bool ok = true;
+    double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);
+    ppi = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
+    pxv[0] = pxv[1] = 0.0;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (j <= i) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = Prow[j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = ppi;
+    }
+    WAVE_SYNC();
+    L.Pxv[i * 2][g] = 0.0, L.Pxv[i * 2 + 1][g] = 0.0;
+    // stage N-1 into buffer (N-1) & 1; inputs u_k, u_{k-1} ride along in registers
+    double pf[NPF];
+    {
+      const double* src = &PG(W.QP, i, N - 1, QP_NF);  // fields i, i + 8, ...: 64 doubles apart
+#pragma unroll
+      for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
+    }
+#pragma unroll
+    for (int j = 0; j < NPF; j++) L.sb[(N - 1) & 1][(i + 8 * j) * 8 + g] = pf[j];
+    double uk[2] = {PL(W.U, 0, N - 1, N), PL(W.U, 1, N - 1, N)};
+    double vk[2];
+    {
+      const int km = N - 2 > 0 ? N - 2 : 0;
+      const double v0 = PL(W.U, 0, km, N), v1 = PL(W.U, 1, km, N);
+      vk[0] = N - 1 > 0 ? v0 : up0, vk[1] = N - 1 > 0 ? v1 : up1;
+    }
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+      // fetch stage k-1 now (branch-free: for k = 0 block 0 is fetched again and dropped), written to the other LDS
+      // buffer at the end of this stage, so that its latency hides behind this stage's arithmetic
+      const int kn = k > 0 ? k - 1 : 0, kv = k > 1 ? k - 2 : 0;
+      const double vn0 = PL(W.U, 0, kv, N), vn1 = PL(W.U, 1, kv, N);
+      WAVE_SYNC();  // the stage block written at the end of the previous stage is visible
+      const double* q = L.sb[k & 1];
+      const double wn = k > 0 ? 1.0 : 0.0;  // the node block of x_0 does not exist (x_0 is data; its slot holds zeros)
+      double Qrow[8], Scol[2], Rm[3], rr[2];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        Qrow[j] = q[(QP_Q + sidx(i, j)) * 8 + g] + ((i == j) ? delta_w : 0.0) + wn * q[(QP_Qx + sidx(i, j)) * 8 + g];
+      Scol[0] = q[(QP_S + i) * 8 + g], Scol[1] = q[(QP_S + 8 + i) * 8 + g];
+      const double qi = q[(QP_q0 + i) * 8 + g] + mu * q[(QP_q1 + i) * 8 + g] + wn * (q[(QP_qx0 + i) * 8 + g] + mu * q[(QP_qx1 + i) * 8 + g]);
+      Rm[0] = q[(QP_R + 0) * 8 + g], Rm[1] = q[(QP_R + 1) * 8 + g], Rm[2] = q[(QP_R + 2) * 8 + g];
+      rr[0] = q[(QP_r0 + 0) * 8 + g] + mu * q[(QP_r1 + 0) * 8 + g], rr[1] = q[(QP_r0 + 1) * 8 + g] + mu * q[(QP_r1 + 1) * 8 + g];
+#define LA(x) q[(QP_A + (x)) * 8 + g]
+#define LB(x) q[(QP_B + (x)) * 8 + g]
+#define Lb(x) q[(QP_b + (x)) * 8 + g]
+      // 1. row i of P A, P B, P b + p
+      double PAr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, PBr[2] = {0, 0}, Pbi = ppi;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) PAr[j] += Prow[l] * LA(l * 8 + j);
+        PBr[0] += Prow[l] * LB(l * 2), PBr[1] += Prow[l] * LB(l * 2 + 1);
+        Pbi += Prow[l] * Lb(l);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = PAr[j];
+      L.PB[i * 2][g] = PBr[0], L.PB[i * 2 + 1][g] = PBr[1], L.Pb[i][g] = Pbi;
+      WAVE_SYNC();
+      // 2. row i of Hxx = Q + A^T (P A), of Hux^T, and gx_i
+      double Hxx[8], Hxu[2], gx = qi;
+#pragma unroll
+      for (int j = 0; j < 8; j++) Hxx[j] = Qrow[j];
+      Hxu[0] = Scol[0], Hxu[1] = Scol[1];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        double ali = LA(l * 8 + i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) Hxx[j] += ali * L.PA[l * 8 + j][g];
+        double pali = L.PA[l * 8 + i][g];
+        Hxu[0] += LB(l * 2) * pali + L.Pxv[l * 2][g] * ali;
+        Hxu[1] += LB(l * 2 + 1) * pali + L.Pxv[l * 2 + 1][g] * ali;
+        gx += ali * L.Pb[l][g];
+      }
+      // (the next stage block is requested here: its 27 registers per lane are live for half a stage only)
+      {
+        const double* src = &PG(W.QP, i, kn, QP_NF);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
+      }
+      // 3. Huu, gu (same numbers in the 8 lanes of an instance)
+      double Huu[4], gu[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
+#pragma unroll
+          for (int l = 0; l < 8; l++)
+            s += LB(l * 2 + c) * L.PB[l * 2 + d][g] + LB(l * 2 + c) * L.Pxv[l * 2 + d][g] + L.Pxv[l * 2 + c][g] * LB(l * 2 + d);
+          Huu[c * 2 + d] = s;
+        }
+        Huu[c * 2 + c] += r2[c] + delta_w;
+        double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
+#pragma unroll
+        for (int l = 0; l < 8; l++) s += LB(l * 2 + c) * L.Pb[l][g] + L.Pxv[l * 2 + c][g] * Lb(l);
+        gu[c] = s;
+      }
+#undef LA
+#undef LB
+#undef Lb
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
+      if (bad && live) ok = false;
+      if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;  // keep the lock-step arithmetic finite
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kc[2], Kv[4], kff[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);  // K[c][i]
+        Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
+        kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
+      }
+      L.K[i][g] = Kc[0], L.K[8 + i][g] = Kc[1];
+      WAVE_SYNC();
+      // 4. cost-to-go of (x_k, v_k)
+      double Pn[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) Pn[j] = Hxx[j] + Hxu[0] * L.K[j][g] + Hxu[1] * L.K[8 + j][g];
+      pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
+      ppi = gx + Hxu[0] * kff[0] + Hxu[1] * kff[1];
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) Pvv[c * 2 + d] = ((c == d) ? r2[c] : 0.0) - r2[c] * Kv[c * 2 + d];
+        pv[c] = gv[c] - r2[c] * kff[c];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = Pn[j];
+      WAVE_SYNC();
+#pragma unroll
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? Pn[j] : 0.5 * (Pn[j] + L.PA[j * 8 + i][g]);
+      L.Pxv[i * 2][g] = pxv[0], L.Pxv[i * 2 + 1][g] = pxv[1];  // read after the next stage's first barrier
+      // the stage block fetched above goes to the other buffer (last read one stage ago), BEFORE this stage's stores
+      // are issued: waiting for the loads then does not wait for the stores
+#pragma unroll
+      for (int j = 0; j < NPF; j++) L.sb[(k & 1) ^ 1][(i + 8 * j) * 8 + g] = pf[j];
+      uk[0] = vk[0], uk[1] = vk[1];  // u_{k-1} is the v of stage k
+      vk[0] = k > 1 ? vn0 : up0, vk[1] = k > 1 ? vn1 : up1;
+      if (live) {
+        PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        if (k > 0) {
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (j <= i) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = Prow[j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = pxv[0], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = pxv[1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
+        }
+      }
+    }
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
+    const bool failed = live && !ok;
+    if (failed) {
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+      if (++tries > 40 || delta_w > 1e20) numerical = true;
+      if (i == 0) STI(SI_NREG) += 1;
+    }
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    if (failed && !again) {  // continue in the next launch (or give up)
+      if (i == 0) {
+        STI(SI_STEP) = 0;
+        if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+        else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = delta_w;
+      }
+      live = false;
+    }
+    if (!__any(again)) break;
+  }
+  if (live && i == 0) {
+    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+    STD(ST_DW) = delta_w;
+    STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
+    STI(SI_STEP) = 1;
+  }
+  if (!__any(live)) return;
+  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles.  A_k, B_k, b_k (88
+  //      fields of the QP block) and the gains (22 fields of the RC block) are staged like the blocks of the sweep.
+  double dxi = 0.0, dv[2] = {0.0, 0.0};
+  if (live) PL(W.dX, i, 0, N + 1) = 0.0;
+  constexpr int NFQ = 11, NFR = 3, FK = 88;  // fields i + 8 j: 11 per lane of A, B, b; 3 per lane of K, Kv, kff (stored at FK..)
+  double fq[NFQ], fr[NFR];
+  {
+    const double* sq = &PG(W.QP, i, 0, QP_NF);
+    const double* sr = &PG(W.RC, i, 0, RC_NF);  // (row 7 reads fields 7, 15, 23: the last one is P, not a gain, never used)
+#pragma unroll
+    for (int j = 0; j < NFQ; j++) fq[j] = sq[j * 64];
+#pragma unroll
+    for (int j = 0; j < NFR; j++) fr[j] = sr[j * 64];
+  }
+  WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < NFQ; j++) L.sb[0][(i + 8 * j) * 8 + g] = fq[j];
+#pragma unroll
+  for (int j = 0; j < NFR; j++) L.sb[0][(FK + i + 8 * j) * 8 + g] = fr[j];  // (FK + 22, FK + 23: unused slots)
+#pragma unroll 1
+  for (int k = 0; k < N; k++) {
+    const int kn = k + 1 < N ? k + 1 : k;
+    {
+      const double* sq = &PG(W.QP, i, kn, QP_NF);
+      const double* sr = &PG(W.RC, i, kn, RC_NF);
+#pragma unroll
+      for (int j = 0; j < NFQ; j++) fq[j] = sq[j * 64];
+#pragma unroll
+      for (int j = 0; j < NFR; j++) fr[j] = sr[j * 64];
+    }
+    WAVE_SYNC();
+    const double* q = L.sb[k & 1];
+    double dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
+    double du[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double s = q[(FK + 20 + c) * 8 + g] + q[(FK + 16 + c * 2) * 8 + g] * dv[0] + q[(FK + 16 + c * 2 + 1) * 8 + g] * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += q[(FK + c * 8 + j) * 8 + g] * dx[j];
+      du[c] = s;
+    }
+    double s = q[(QP_b + i) * 8 + g] + q[(QP_B + i * 2) * 8 + g] * du[0] + q[(QP_B + i * 2 + 1) * 8 + g] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += q[(QP_A + i * 8 + j) * 8 + g] * dx[j];
+    dxi = s;
+    dv[0] = du[0], dv[1] = du[1];
+#pragma unroll
+    for (int j = 0; j < NFQ; j++) L.sb[(k & 1) ^ 1][(i + 8 * j) * 8 + g] = fq[j];
+#pragma unroll
+    for (int j = 0; j < NFR; j++) L.sb[(k & 1) ^ 1][(FK + i + 8 * j) * 8 + g] = fr[j];
+    if (live) {
+      PL(W.dX, i, k + 1, N + 1) = dxi;
+      if (i < 2) PL(W.dU, i, k, N) = du[i];
+    }
+  }
+}
+
+// ---- single-instance form of the sweep (k_riccati1): all 64 lanes work on ONE instance, lane (g, i) computes column g of
+// row i of the 8x8 products instead of all 8 columns, with the SAME per-element expressions as d_riccati8, so that the
+// bits do not depend on which of the two a solve goes through.  LDS slot [field][0] is shared by the 8 column lanes.
+struct Stage1Regs {
+  double a, bb, b, q_elem, S[2], q, R[3], r[2], u[2], v[2];
+};
+// Stage data of the ONE instance of a k_riccati1 block, staged in LDS once per launch: with a single wavefront per
+// instance the sweep is a chain of N dependent stages, and fetching each stage from HBM/L2 (even one stage ahead) costs
+// more than the stage's arithmetic.  q: [N][QP_NF] (copy of the instance's QP blocks), u: [N][2], kk: [N][22] gains.
+// element i (run-time) of a register array: selects instead of an indexed (scratch) access
+__device__ __forceinline__ double sel8(const double* a, const int i) {
+  double r = a[0];
+#pragma unroll
+  for (int j = 1; j < 8; j++) r = (i == j) ? a[j] : r;
+  return r;
+}
+struct StageLds {  // views into the dynamic LDS of a k_riccati1 block
+  double* q;   // [N][QP_NF]
+  double* u;   // [N][2]
+  double* kk;  // [N][22]
+};
+struct Ric1Lds {
+  double PA[64], PB[16], Pb[8], K[16], P[64], Pxv[16];
+};
+__host__ __device__ constexpr size_t ric1_lds_bytes(int N) { return sizeof(double) * (size_t)N * (QP_NF + 24) + sizeof(Ric1Lds); }
+__device__ __forceinline__ void load_stage1(const StageLds& S, const double p0, const double p1, int i, int g, int k, double mu,
+                                            double delta_w, Stage1Regs& s) {
+  const int km = k > 0 ? k - 1 : 0;
+  const double wn = k > 0 ? 1.0 : 0.0;
+  const double* q = S.q + k * QP_NF;
+  s.a = q[QP_A + i * 8 + g];
+  s.bb = q[QP_B + i * 2 + (g & 1)];
+  s.b = q[QP_b + i];
+  const double qa = q[QP_Q + sidx(i, g)], qb = q[QP_Qx + sidx(i, g)];
+  s.S[0] = q[QP_S + i], s.S[1] = q[QP_S + 8 + i];
+  const double q0 = q[QP_q0 + i], q1 = q[QP_q1 + i];
+  const double x0 = q[QP_qx0 + i], x1 = q[QP_qx1 + i];
+  s.R[0] = q[QP_R + 0], s.R[1] = q[QP_R + 1], s.R[2] = q[QP_R + 2];
+  const double r00 = q[QP_r0 + 0], r01 = q[QP_r0 + 1];
+  const double r10 = q[QP_r1 + 0], r11 = q[QP_r1 + 1];
+  s.u[0] = S.u[k * 2], s.u[1] = S.u[k * 2 + 1];
+  const double v0 = S.u[km * 2], v1 = S.u[km * 2 + 1];
+  s.q_elem = qa + ((i == g) ? delta_w : 0.0) + wn * qb;
+  s.q = q0 + mu * q1 + wn * (x0 + mu * x1);
+  s.r[0] = r00 + mu * r10, s.r[1] = r01 + mu * r11;
+  s.v[0] = k > 0 ? v0 : p0, s.v[1] = k > 0 ? v1 : p1;
+}
+
+__device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1Lds& L, const StageLds& S, const int g, const int i, const int b,
+                                           const bool valid, const int active_slot, const int max_sweeps) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  const ltompc_options& o = K.o;
+  // LTOMPC_DBG: shader-clock cycles of block 0 per section (head, staging, backward sweeps, forward), summed over launches
+  const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  long long rt0 = rprof ? clock64() : 0;
+#define RTOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
+  bool live = valid && !STI(SI_DONE);
+  if (!__any(live)) return;
+  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
+  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
+  // than one sweep however hard the worst instance of the batch is.
+  const bool retry = live && STI(SI_RETRY);
+  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
+  //      every lane (identical to the serial kernel, so that both produce the same bits)
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
+  for (int k = i; k < N; k += 8) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+  }
+  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
+  double smult = 0.0, obj;
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
+  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  double mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  int term = -1;
+  if (live && !retry) {
+    int iters = STI(SI_ITERS);
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
+      if (i == 0) STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (i == 0) {
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+    }
+    if (term >= 0) live = false;
+  }
+  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
+  if (!__any(live)) return;
+  // ---- monotone barrier update
+  bool mu_changed = false;
+  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (live && !retry && i == 0) {
+    if (mu_changed) {
+      STD(ST_MU) = mu;
+      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+    }
+    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  }
+  // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
+  //      the others recompute the same numbers)
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  double delta_w = STD(ST_FORCE_REG);
+  const double dw_last = STD(ST_DW_LAST);
+  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  int tries = 0;
+  if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
+  bool numerical = false;
+  // max_sweeps = 1 while the launch is wide (a launch then never takes longer than one sweep, however hard the worst
+  // instance of the batch is: its further attempts happen in the following launches); a few attempts per launch
+  // once only the stragglers are left
+  RTOCK(0);
+  // stage the instance's QP blocks and inputs in LDS (all 64 lanes, independent loads)
+  {
+    const int lane = i * 8 + g;
+    const int total = N * QP_NF;
+    for (int base = lane; base < total; base += 64 * 8) {  // 8 independent loads in flight per lane
+      double v[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int idx = base + 64 * r, ic = idx < total ? idx : total - 1;
+        const int kq = ic / QP_NF, fq = ic - kq * QP_NF;
+        v[r] = PG(W.QP, fq, kq, QP_NF);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++)
+        if (base + 64 * r < total) S.q[base + 64 * r] = v[r];
+    }
+    for (int idx = lane; idx < N * 2; idx += 64) S.u[idx] = PL(W.U, idx & 1, idx >> 1, N);
+  }
+  WAVE_SYNC();
+  RTOCK(1);
+  // (read once: a global load inside the stage loop would wait, on vmcnt, for the RC stores of the previous stage)
+  const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
+  mu = __shfl(mu, 8 * i);  // the column lanes (g > 0) do real work here: give them the live lane's barrier parameter
+  for (int sweep = 0;; sweep++) {
+    delta_w = __shfl(delta_w, 8 * i);  // ... and its regularisation
+    bool ok = true;
+    double Prow[8], pxv[2], ppi, Pvv[4] = {0, 0, 0, 0}, pv[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) Prow[j] = PG(W.QP, QP_Qx + sidx(i, j), N, QP_NF) + ((i == j) ? delta_w : 0.0);  // (terminal node: not staged)
+    ppi = PG(W.QP, QP_qx0 + i, N, QP_NF) + mu * PG(W.QP, QP_qx1 + i, N, QP_NF);
+    pxv[0] = pxv[1] = 0.0;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if (j <= i) PG(W.RC, RC_P + sidx(i, j), N, RC_NF) = Prow[j];
+      PG(W.RC, RC_Pxv + i * 2, N, RC_NF) = 0.0, PG(W.RC, RC_Pxv + i * 2 + 1, N, RC_NF) = 0.0;
+      PG(W.RC, RC_pp + i, N, RC_NF) = ppi;
+    }
+    WAVE_SYNC();
+    L.Pxv[i * 2] = 0.0, L.Pxv[i * 2 + 1] = 0.0;
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+      Stage1Regs cur;
+      load_stage1(S, up0, up1, i, g, k, mu, delta_w, cur);
+      const double Rm[3] = {cur.R[0], cur.R[1], cur.R[2]}, rr[2] = {cur.r[0], cur.r[1]};
+      const double uk[2] = {cur.u[0], cur.u[1]}, vk[2] = {cur.v[0], cur.v[1]};
+      const double* qk = S.q + k * QP_NF;  // A_k, B_k, b_k are read in place
+      // 1. element (i, g) of P A, element (i, g < 2) of P B, P b + p (same expressions as d_riccati8, one column per lane).
+      //    Every phase first pulls what it needs from LDS into registers, branch-free, and then computes: a wave waits
+      //    once per phase instead of once per operand.
+      double Ag[8], Bg[8], bl[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) Ag[l] = qk[QP_A + l * 8 + g], Bg[l] = qk[QP_B + l * 2 + (g & 1)], bl[l] = qk[QP_b + l];
+      double pa = 0.0, pb = 0.0, Pbi = ppi;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        pa += Prow[l] * Ag[l];
+        pb += Prow[l] * Bg[l];  // (lanes g >= 2 repeat column g & 1 and drop it)
+        Pbi += Prow[l] * bl[l];
+      }
+      L.PA[i * 8 + g] = pa;
+      if (g < 2) L.PB[i * 2 + g] = pb;
+      L.Pb[i] = Pbi;
+      WAVE_SYNC();
+      // 2. element (i, g) of Hxx, row i of Hux^T, gx_i
+      double Ai[8], PAg[8], PAi[8], B0[8], B1[8], X0[8], X1[8], Pbv[8];
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        Ai[l] = qk[QP_A + l * 8 + i], PAg[l] = L.PA[l * 8 + g], PAi[l] = L.PA[l * 8 + i];
+        B0[l] = qk[QP_B + l * 2], B1[l] = qk[QP_B + l * 2 + 1], X0[l] = L.Pxv[l * 2], X1[l] = L.Pxv[l * 2 + 1];
+        Pbv[l] = L.Pb[l];
+      }
+      double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
+#pragma unroll
+      for (int l = 0; l < 8; l++) {
+        double ali = Ai[l];
+        hxx += ali * PAg[l];
+        double pali = PAi[l];
+        Hxu[0] += B0[l] * pali + X0[l] * ali;
+        Hxu[1] += B1[l] * pali + X1[l] * ali;
+        gx += ali * Pbv[l];
+      }
+      // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles.
+      //    Both sums are formed by every lane with selected operands (no divergent branches, no run-time indices into
+      //    register arrays: those would live in scratch, and a scratch reload waits for the RC stores of the stage before)
+      double he;
+      {
+        const bool c1 = (g >> 1) & 1, d1 = g & 1;
+        const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);     // Rm[sidx(c, d)]
+        const double pvv = c1 ? (d1 ? Pvv[3] : Pvv[2]) : (d1 ? Pvv[1] : Pvv[0]);  // Pvv[c * 2 + d]
+        double PBd[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) PBd[l] = L.PB[l * 2 + (g & 1)];
+        double s = rm + pvv;
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          const double Bc = c1 ? B1[l] : B0[l], Bd = d1 ? B1[l] : B0[l], Xc = c1 ? X1[l] : X0[l], Xd = d1 ? X1[l] : X0[l];
+          s += Bc * PBd[l] + Bc * Xd + Xc * Bd;
+        }
+        double heH = s;
+        if (c1 == d1) heH += (c1 ? r2[1] : r2[0]) + delta_w;
+        // gu[c], c = g & 1
+        double sg = (d1 ? rr[1] : rr[0]) + (d1 ? r2[1] : r2[0]) * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          const double Bc = d1 ? B1[l] : B0[l], Xc = d1 ? X1[l] : X0[l];
+          sg += Bc * Pbv[l] + Xc * bl[l];
+        }
+        he = g < 4 ? heH : (g < 6 ? sg : 0.0);
+      }
+      double Huu[4], gu[2];
+#pragma unroll
+      for (int q = 0; q < 4; q++) Huu[q] = __shfl(he, q + 8 * i);
+      gu[0] = __shfl(he, 4 + 8 * i), gu[1] = __shfl(he, 5 + 8 * i);
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
+      if (bad && live) ok = false;
+      if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;
+      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      double Kc[2], Kv[4], kff[2];
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);  // K[c][i]
+        Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
+        kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
+      }
+      L.K[i] = Kc[0], L.K[8 + i] = Kc[1];
+      WAVE_SYNC();
+      // 4. cost-to-go: element (i, g)
+      const double pn = hxx + Hxu[0] * L.K[g] + Hxu[1] * L.K[8 + g];
+      pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
+      ppi = gx + Hxu[0] * kff[0] + Hxu[1] * kff[1];
+      double gv[2] = {-r2[0] * (uk[0] - vk[0]), -r2[1] * (uk[1] - vk[1])};
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int d = 0; d < 2; d++) Pvv[c * 2 + d] = ((c == d) ? r2[c] : 0.0) - r2[c] * Kv[c * 2 + d];
+        pv[c] = gv[c] - r2[c] * kff[c];
+      }
+      L.P[i * 8 + g] = pn;
+      WAVE_SYNC();
+#pragma unroll
+      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? L.P[i * 8 + j] : 0.5 * (L.P[i * 8 + j] + L.P[j * 8 + i]);
+      L.Pxv[i * 2] = pxv[0], L.Pxv[i * 2 + 1] = pxv[1];
+      if (g == 0) {  // the gains stay in LDS for the forward rollout (same numbers in all column lanes)
+        S.kk[k * 22 + i] = Kc[0], S.kk[k * 22 + 8 + i] = Kc[1];
+        if (i < 4) S.kk[k * 22 + 16 + i] = Kv[i];
+        if (i < 2) S.kk[k * 22 + 20 + i] = kff[i];
+      }
+      if (live) {
+        PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        if (k > 0) {
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            if (j <= i) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = Prow[j];
+          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = pxv[0], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = pxv[1];
+          PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
+        }
+      }
+    }
+    // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
+    const bool failed = live && !ok;
+    if (failed) {
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
+      if (++tries > 40 || delta_w > 1e20) numerical = true;
+      if (i == 0) STI(SI_NREG) += 1;
+    }
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    if (failed && !again) {  // continue in the next launch (or give up)
+      if (i == 0) {
+        STI(SI_STEP) = 0;
+        if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+        else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = delta_w;
+      }
+      live = false;
+    }
+    if (!__any(again)) break;
+  }
+  RTOCK(2);
+  if (live && i == 0) {
+    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+    STD(ST_DW) = delta_w;
+    STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
+    STI(SI_STEP) = 1;
+  }
+  if (!__any(live)) return;
+  // ---- forward rollout: lane (g,i) carries dx_i; the full vector is gathered with wave shuffles
+  double dxi = 0.0, dv[2] = {0.0, 0.0};
+  if (live) PL(W.dX, i, 0, N + 1) = 0.0;
+  WAVE_SYNC();
+#pragma unroll 1
+  for (int k = 0; k < N; k++) {
+    FwdRegs fc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) fc.K[j] = S.kk[k * 22 + j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fc.Kv[j] = S.kk[k * 22 + 16 + j];
+    fc.kff[0] = S.kk[k * 22 + 20], fc.kff[1] = S.kk[k * 22 + 21];
+#pragma unroll
+    for (int j = 0; j < 8; j++) fc.A[j] = S.q[k * QP_NF + QP_A + i * 8 + j];
+    fc.B[0] = S.q[k * QP_NF + QP_B + i * 2], fc.B[1] = S.q[k * QP_NF + QP_B + i * 2 + 1];
+    fc.b = S.q[k * QP_NF + QP_b + i];
+    double dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
+    double du[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double s = fc.kff[c] + fc.Kv[c * 2] * dv[0] + fc.Kv[c * 2 + 1] * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += fc.K[c * 8 + j] * dx[j];
+      du[c] = s;
+    }
+    double s = fc.b + fc.B[0] * du[0] + fc.B[1] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += fc.A[j] * dx[j];
+    dxi = s;
+    dv[0] = du[0], dv[1] = du[1];
+    if (live) {
+      PL(W.dX, i, k + 1, N + 1) = dxi;
+      if (i < 2) PL(W.dU, i, k, N) = du[i];
+    }
+  }
+  RTOCK(3);
+  if (rprof) W.DBG[4] += 1.0;
+#undef RTOCK
+}
+
+__global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
+  __shared__ RicLds L;
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  const int jj = blockIdx.x * 8 + g;
+  const bool valid = jj < la.nact[0];
+  d_riccati8(K, W, L, g, i, la.act[valid ? jj : 0], valid, it_index, max_sweeps);
+}
+
+// One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
+// sweep, and 8 instances per wavefront make that sweep ~3x longer than it has to be).  Dynamic LDS: ric1_lds_bytes(N).
+__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, Launch la, int it_index) {
+  extern __shared__ double lds1[];
+  const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
+  if ((int)blockIdx.x >= la.nact[0]) return;
+  const int N = W.N;
+  StageLds S{lds1, lds1 + (size_t)N * QP_NF, lds1 + (size_t)N * (QP_NF + 2)};
+  Ric1Lds& L = *reinterpret_cast<Ric1Lds*>(lds1 + (size_t)N * (QP_NF + 24));
+  d_riccati1(K, W, L, S, g, i, la.act[blockIdx.x], g == 0, it_index, 1);
+}
+
+
+}  // namespace ltompc
