@@ -18,13 +18,25 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libltompc.so (in-tree, so that it travels with the repo snapshot)."""
+    """hipcc --offload-arch=gfx950 -> csrc/libltompc.so (in-tree, so that it travels with the repo snapshot).
+
+    Several processes may call this at once (one rank per GPU under torchrun): the build is serialised with a file lock
+    and written to a temporary name first, so that nobody loads a half-written library."""
     if not force and not needs_build():
         return LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=on",
-           os.path.join(CSRC, "ltompc.hip"), "-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or needs_build():  # (somebody else may have built it while we waited)
+                hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+                tmp = LIB + f".tmp{os.getpid()}"
+                cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-ffp-contract=on",
+                       os.path.join(CSRC, "ltompc.hip"), "-o", tmp]
+                if verbose:
+                    print(" ".join(cmd))
+                subprocess.check_call(cmd, cwd=CSRC)
+                os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB

@@ -33,9 +33,9 @@ class Options(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "ltompc_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    srcs = [os.path.join(_HERE, "ltompc_oracle.c"), os.path.join(_HERE, "..", "include", "ltompc.h")]  # (the structs)
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
 
