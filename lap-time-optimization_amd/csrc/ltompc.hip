@@ -159,7 +159,7 @@ int planes_to_host(ltompc_solver* h, const double* dev, int F, int NK, double* o
 extern "C" {
 
 const char* ltompc_last_error(void) { return g_err.c_str(); }
-const char* ltompc_version(void) { return "ltompc 0.2 (gfx950, fp64; thread-per-interval evaluation, wave-cooperative Riccati)"; }
+const char* ltompc_version(void) { return "ltompc 0.3 (gfx950, fp64; block-structured interval evaluation, LDS-staged wave-cooperative Riccati)"; }
 
 void ltompc_default_params(ltompc_params* p) {
   std::memset(p, 0, sizeof *p);
