@@ -369,3 +369,53 @@ def test_handles_with_different_horizons_coexist(pkg, tables, oracle, gpu_lib):
     assert a.status[0] == 0 and b.status[0] == 0
     assert np.abs(ua - oracle.solve(x, 60)["u0"]).max() < 1e-7 and np.abs(ub - oracle.solve(x, 10)["u0"]).max() < 1e-7
     a.close(); b.close()
+
+
+def test_warm_reset_after_a_failed_solve(pkg, tables, orc, gpu_lib):
+    """options.warm_reset_on_fail: after a solve that did not converge the next tick keeps the primal point but restarts
+    multipliers and barrier; the GPU and the oracle (prev_status) do the same thing under both settings."""
+    B, N = 16, 20
+    x0 = pkg.sample_x0(tables, B, seed=11)
+    # a first tick that fails: an infeasible start 30 m off the track; then back on the track
+    xbad = x0.copy(); xbad[:, 1] += 30.0
+    res = {}
+    for reset in (0, 1):
+        o = pkg.default_options(); o.max_iter, o.warm_reset_on_fail = 200, reset
+        oo = orc.default_options(); oo.max_iter, oo.warm_reset_on_fail = 200, reset
+        oracle = orc.Oracle(tables.packed(), options=oo)
+        mm = pkg.BatchedMPC(tables, N, B, options=o)
+        mm.set_initial_guess(xbad)
+        mm.make_step(xbad)
+        r1 = oracle.solve(xbad, N, nthreads=8)
+        assert (mm.status != 0).mean() > 0.8 and np.array_equal(mm.status != 0, r1["status"] != 0)
+        u2 = mm.make_step(x0)   # back on the track: warm start from the failed solve
+        r2 = oracle.solve(x0, N, uprev=r1["u0"], warm=r1, nthreads=8, prev_status=r1["status"])
+        both = (mm.status == 0) & (r2["status"] == 0)
+        assert both.mean() > 0.6, (reset, both.mean())
+        assert np.abs(u2 - r2["u0"])[both].max() < 1e-5
+        assert (np.abs(mm.iters - r2["iters"])[both] <= 2).mean() > 0.8
+        res[reset] = (mm.iters.copy(), mm.status.copy())
+        mm.close()
+    # the reset is not a no-op: iteration counts differ between the two policies
+    assert not np.array_equal(res[0][0], res[1][0])
+
+
+def test_profiling_api(pkg, tables, gpu_lib):
+    """ltompc_set_profiling / get_timing / get_launch_log: per-launch log consistent with the per-class totals."""
+    B, N = 40, 10
+    x0 = pkg.sample_x0(tables, B, seed=2)
+    o = pkg.default_options(); o.latency_mode = 2
+    m = pkg.BatchedMPC(tables, N, B, options=o)
+    m.set_initial_guess(x0)
+    m.set_profiling(True)
+    m.make_step(x0)
+    tm = m.timing()
+    kind, width, ms = m.launch_log()
+    names = list(tm["ms"].keys())
+    assert len(names) == 8 and kind.size == sum(tm["launches_by_kernel"].values()) and kind.size > 20
+    for q, nm in enumerate(names):
+        assert abs(ms[kind == q].sum() - tm["ms"][nm]) < 1e-6 * max(1.0, tm["ms"][nm])
+    assert width.max() == B and (ms > 0).all() and tm["ip_iterations"] >= int(m.iters.max())
+    assert tm["launches_by_kernel"]["riccati1"] > 0 and tm["launches_by_kernel"]["step1"] > 0  # narrow launches (B <= 512)
+    m.set_profiling(False)
+    m.close()
