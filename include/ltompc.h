@@ -80,6 +80,14 @@ typedef struct ltompc_options {
    * is what do_mpc/IPOPT do (IPOPT restarts at mu_init = 0.1 on every call); a smaller value (1e-3 .. 1e-2) keeps
    * the iterates close to the previous solution and saves iterations without changing the KKT point found. */
   double mu_init_warm;    /* 0 */
+  /* Softened track constraints (do_mpc: set_nl_cons(..., soft_constraint=True, penalty_term_cons=soft_rho)).
+   * 0 = hard constraints gL, gR <= 0 as in the reference (controller.py:69-70).  > 0: every track constraint of every
+   * node gets an elastic variable e >= 0 (g - e <= 0) that costs soft_rho * e (exact L1 penalty: the solution is the
+   * hard-constrained one wherever that exists and soft_rho exceeds its multipliers, and a least-violation one where
+   * the track is narrower than the car, e.g. the chicane of buckmore at s = 405 m where the hard problem is
+   * infeasible and the reference's closed loop stops).  The elastic variables are eliminated with the slacks:
+   * same stage-QP sizes, same kernels, three more planes per interval. */
+  double soft_rho;        /* 0 */
   int max_iter;           /* controller.py:18 says 1000 */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */

@@ -53,8 +53,11 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   double gv[3] = {-1.0, -1.0, -1.0};
   if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
   for (int q = 0; q < 3; q++) {
-    const double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push;
-    PL(W.T, m + q, k, N) = t, PL(W.NU, m + q, k, N) = mu / t;
+    double hq = gv[q], e = 0.0;
+    if (K.o.soft_rho > 0.0 && k + 1 <= N - 1) e = fmax(gv[q] + K.o.bound_push, mu / K.o.soft_rho), hq -= e;  // g - e + t = 0
+    const double t = -hq > K.o.bound_push ? -hq : K.o.bound_push;
+    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e;
+    PL(W.NU, m + q, k, N) = (K.o.soft_rho > 0.0) ? fmin(mu / t, 0.5 * K.o.soft_rho) : mu / t;  // soft: 0 < nu < rho
   }
   if (k == 0) {
     double* st = W.st;

@@ -54,6 +54,7 @@ struct Lin8 {  // what lane (g, i) holds of its slot after lin8()
   double cost;                  // node cost (same in all lanes)
   double gv[3], gs[3], gn[3], gm[3];  // track constraints at x+ (same in all lanes)
   double rp_ineq, cmax, cmin, smult, th_ineq, sumlog;  // DUAL: per-lane partials over the inequalities this lane owns
+  double csoft;                 // DUAL: penalty rho e of the soft track constraint this lane owns
   double Yr[11], ABr[11];       // rows i of [Ac | Bc | bc] and [A | B | b]
   double Mir[8];                // EXPAND: row i of M8^-1
   int m_nl;
@@ -64,7 +65,7 @@ template <bool DUAL, bool EXPAND>
 __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, const int i, const int k, const int b,
                                      const double eps, Lin8& S) {
   const int N = W.N;
-  const double hdt = K.o.t_step;
+  const double hdt = K.o.t_step, rho = K.o.soft_rho;
   const int pt = i >> 2;  // 0: this lane evaluates the model at c_k, 1: at x_{k+1}
   // ---- inputs
   double px[8], lam[8];
@@ -119,7 +120,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
   // ---- inequalities: the lane that owns component j adds the barrier terms of the bounds on it
   S.gc0 = 0.0, S.gc1 = 0.0, S.gx0 = S.gcost, S.gx1 = 0.0, S.dcd = 0.0, S.dxd = S.gcost;
   S.Du = 0.0, S.gub0 = 0.0, S.gub1 = 0.0, S.dud = 0.0;
-  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0, S.csoft = 0.0;
   double hcd = 0.0, hxd = 0.0;  // additions to the diagonal entries Hc[i][i], Hx+[i][i]
   double lprod = 1.0;           // product of the slacks this lane owns (at most 6): one logarithm per lane
   S.m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
@@ -148,12 +149,14 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       const int mm = S.m_nl + q;
-      const double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N), it = 1.0 / t;
-      const double Sg = nu * it, s0 = nu * (S.gv[q] + t) * it;
+      const double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N);
+      const double e = rho > 0.0 ? PL(W.T, mm + 3, k, N) : 0.0;
+      double Sg, s0, s1;
+      track_barrier(rho, S.gv[q], t, nu, e, Sg, s0, s1);
       const double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
       const double ga = i == 0 ? g3[0] : (i == 1 ? g3[1] : g3[2]);
       if (i < 3) {
-        S.gx0 += s0 * ga, S.gx1 += it * ga;
+        S.gx0 += s0 * ga, S.gx1 += s1 * ga;
         if (DUAL) S.dxd += nu * ga;
 #pragma unroll
         for (int c = 0; c < 3; c++) S.Hxr[c] += Sg * ga * g3[c];
@@ -161,9 +164,14 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
       if (i == 0) S.Hxr[0] += nu * hss[q];
       if (i == 2) S.Hxr[2] += nu * hmm[q];
       if (DUAL && i == q) {
-        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
+        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] - e + t));
         S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-        S.th_ineq += fabs(S.gv[q] + t), lprod *= t;
+        S.th_ineq += fabs(S.gv[q] - e + t), lprod *= t;
+        if (rho > 0.0) {
+          const double ez = e * (rho - nu);
+          S.cmax = fmax(S.cmax, ez), S.cmin = fmin(S.cmin, ez), S.smult += fabs(rho - nu);
+          lprod *= e, S.csoft = rho * e;
+        }
       }
     }
   }
@@ -268,7 +276,7 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
     }
     rd = grp_max(rd), rp = grp_max(rp), sm = grp_sum(sm);
     const double cmax = grp_max(S.cmax), cmin = grp_min(S.cmin);
-    const double cost = S.cost + grp_sum(cost_u);
+    const double cost = S.cost + grp_sum(cost_u + S.csoft);
     const double th0 = grp_sum(S.th_ineq + fabs(S.G1) + fabs(S.G2)), sumlog = grp_sum(S.sumlog);
     if (live && i == 0) {
       PL(W.LS, 0, k, N) = th0, PL(W.LS, 1, k, N) = cost, PL(W.LS, 2, k, N) = sumlog;
@@ -421,14 +429,21 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
       const double gnq = i == 0 ? S.gn[0] : (i == 1 ? S.gn[1] : S.gn[2]);
       const double gmq = i == 0 ? S.gm[0] : (i == 1 ? S.gm[1] : S.gm[2]);
       const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
-      const double dtt = -(gvq + t) - (gsq * dxp[0] + gnq * dxp[1] + gmq * dxp[2]);
-      const double dn = (mu - nu * dtt) * it - nu;
-      if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-      r_pri = fmax(r_pri, -dtt * it);
-      if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-      gphid -= mu * dtt * it;
+      const double gd = gsq * dxp[0] + gnq * dxp[1] + gmq * dxp[2];
+      if (K.o.soft_rho > 0.0) {
+        double dtt, dn, dee;
+        track_soft_step(K.o.soft_rho, mu, tau, gvq, gd, t, nu, PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
+      } else {
+        const double dtt = -(gvq + t) - gd;
+        const double dn = (mu - nu * dtt) * it - nu;
+        if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+        r_pri = fmax(r_pri, -dtt * it);
+        if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+        gphid -= mu * dtt * it;
+      }
     } else if (live) {
-      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0, PL(W.dT, m + 3, k, N) = 0.0;
     }
   }
   r_pri = grp_max(r_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);

@@ -32,6 +32,41 @@ __device__ __forceinline__ int for_each_bound(const ltompc_params& p, F&& f) {
   return m;  // index of the first track constraint
 }
 
+// ------------------------------------------------------------------------------------------ track constraints
+// Barrier terms of one track constraint g <= 0 with slack t and multiplier nu: Hessian weight Sg on grad g grad g^T,
+// gradient multiplier s0 + mu s1.  Hard (rho = 0): g + t = 0.  Soft (options.soft_rho = rho > 0): g - e + t = 0 with
+// the elastic variable e >= 0 that costs rho e; its bound multiplier is z = rho - nu (stationarity in e is linear, so
+// z needs no storage), and eliminating (dt, de, dnu) from the Newton system
+//   grad g . dx - de + dt = -(g - e + t) ,  t dnu + nu dt = mu - t nu ,  -e dnu + z de = mu - e z
+// gives dnu = Sg (grad g . dx + g + mu / nu - mu / z) with Sg = 1 / (t / nu + e / z).
+__device__ __forceinline__ void track_barrier(const double rho, const double gv, const double t, const double nu,
+                                              const double e, double& Sg, double& s0, double& s1) {
+  if (rho > 0.0) {
+    const double inu = 1.0 / nu, iz = 1.0 / (rho - nu);
+    Sg = 1.0 / (t * inu + e * iz), s0 = nu + Sg * gv, s1 = Sg * (inu - iz);
+  } else {
+    const double it = 1.0 / t;
+    Sg = nu * it, s0 = nu * (gv + t) * it, s1 = it;
+  }
+}
+// steps of (t, nu, e) of a soft track constraint from gd = grad g . dx (see track_barrier), the bounds they put on the
+// step lengths (r_pri = max(-dt / t, -de / e); 0 < nu + a dnu < rho) and their part of the directional derivative of
+// the barrier objective
+__device__ __forceinline__ void track_soft_step(const double rho, const double mu, const double tau, const double gv,
+                                                const double gd, const double t, const double nu, const double e,
+                                                double& dtt, double& dn, double& dee, double& r_pri, double& a_dua,
+                                                double& gphid) {
+  const double z = rho - nu, inu = 1.0 / nu, iz = 1.0 / z, it = 1.0 / t, ie = 1.0 / e;
+  const double Sg = 1.0 / (t * inu + e * iz);
+  dn = Sg * (gd + gv + mu * inu - mu * iz);
+  dtt = mu * inu - t - t * inu * dn;
+  dee = mu * iz - e + e * iz * dn;
+  r_pri = fmax(r_pri, fmax(-dtt * it, -dee * ie));
+  if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+  if (dn > 0.0) a_dua = fmin(a_dua, tau * z / dn);
+  gphid += rho * dee - mu * dtt * it - mu * dee * ie;
+}
+
 // ------------------------------------------------------------------------------------------ slot linearisation
 // Slot k owns (u_k, c_k, x_{k+1}) and the collocation equations of interval k in do_mpc's Radau-IIA(2) form
 //   G1 = h f(c,u) + 2 x_k - 1.5 c - 0.5 x+ = 0 ,  G2 = h f(x+,u) - 2 x_k + 4.5 c - 2.5 x+ = 0   
@@ -55,7 +90,7 @@ struct Slot {
 template <bool WITH_DUAL>
 __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
   const int N = W.N;
-  const double hdt = K.o.t_step;
+  const double hdt = K.o.t_step, rho = K.o.soft_rho;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     S.xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
@@ -124,12 +159,14 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int mm = m_nl + q;
-      double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N), it = 1.0 / t;
-      double Sg = nu * it, s0 = nu * (S.gv[q] + t) * it;
+      double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N);
+      const double e = rho > 0.0 ? PL(W.T, mm + 3, k, N) : 0.0;  // soft: elastic variable, stored after the slacks
+      double Sg, s0, s1;
+      track_barrier(rho, S.gv[q], t, nu, e, Sg, s0, s1);
       double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        S.gxp0[a] += s0 * g3[a], S.gxp1[a] += it * g3[a];
+        S.gxp0[a] += s0 * g3[a], S.gxp1[a] += s1 * g3[a];
         if (WITH_DUAL) S.dxd[a] += nu * g3[a];
 #pragma unroll
         for (int c = 0; c <= a; c++) S.Hxp[sidx(a, c)] += Sg * g3[a] * g3[c];
@@ -137,9 +174,14 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
       S.Hxp[sidx(0, 0)] += nu * hss[q];
       S.Hxp[sidx(2, 2)] += nu * hmm[q];
       if (WITH_DUAL) {
-        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] + t));
+        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gv[q] - e + t));
         S.cmax = fmax(S.cmax, t * nu), S.cmin = fmin(S.cmin, t * nu), S.smult += fabs(nu);
-        S.th_ineq += fabs(S.gv[q] + t), lprod *= t;
+        S.th_ineq += fabs(S.gv[q] - e + t), lprod *= t;
+        if (rho > 0.0) {
+          const double ez = e * (rho - nu);
+          S.cmax = fmax(S.cmax, ez), S.cmin = fmin(S.cmin, ez), S.smult += fabs(rho - nu);
+          lprod *= e, S.cost += rho * e;
+        }
         if ((mm & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
       }
     }
@@ -493,14 +535,21 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
     const int m = S.m_nl + q;
     if (S.nl) {
       const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
-      const double dtt = -(S.gv[q] + t) - (S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2]);
-      const double dn = (mu - nu * dtt) * it - nu;
-      PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
-      r_pri = fmax(r_pri, -dtt * it);
-      if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
-      gphid -= mu * dtt * it;
+      const double gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
+      if (K.o.soft_rho > 0.0) {
+        double dtt, dn, dee;
+        track_soft_step(K.o.soft_rho, mu, tau, S.gv[q], gd, t, nu, PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
+      } else {
+        const double dtt = -(S.gv[q] + t) - gd;
+        const double dn = (mu - nu * dtt) * it - nu;
+        PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
+        r_pri = fmax(r_pri, -dtt * it);
+        if (dn < 0.0) a_dua = fmin(a_dua, -tau * nu / dn);
+        gphid -= mu * dtt * it;
+      }
     } else {
-      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0;
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0, PL(W.dT, m + 3, k, N) = 0.0;
     }
   }
   const double a_pri = r_pri > tau ? tau / r_pri : 1.0;

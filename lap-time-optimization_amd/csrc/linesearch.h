@@ -69,7 +69,13 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
-        th += fabs(gv[q] + t), pr *= t;
+        double e = 0.0;
+        pr *= t;
+        if (K.o.soft_rho > 0.0) {  // elastic variable of the softened constraint: g - e + t = 0, cost rho e
+          e = PL(W.T, m + 3 + q, k, N) + alpha * PL(W.dT, m + 3 + q, k, N);
+          pr *= e, co += K.o.soft_rho * e;
+        }
+        th += fabs(gv[q] - e + t);
         if (((m + q) & 7) == 7) sl += log(pr), pr = 1.0;
       }
     }
@@ -256,6 +262,8 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
     double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
     PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
   }
+  if (K.o.soft_rho > 0.0 && nact == ni)
+    for (int m = ni; m < ni + 3; m++) PL(W.T, m, k, N) += alpha * PL(W.dT, m, k, N);  // elastic variables
 }
 
 __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {

@@ -199,6 +199,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (batch < 1) return fail("ltompc_create: batch must be >= 1");
   if (options->n_linesearch < 1 || options->n_linesearch > MAX_LS) return fail("ltompc_create: n_linesearch out of range");
   if (!(options->t_step > 0)) return fail("ltompc_create: t_step must be positive");
+  if (!(options->soft_rho >= 0) || !std::isfinite(options->soft_rho)) return fail("ltompc_create: soft_rho must be >= 0 (0 = hard track constraints)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
     for (int i = 0; i < n_table; i++)
       if (!std::isfinite(tables[(size_t)r * n_table + i])) return fail("ltompc_create: non-finite table entry");
@@ -249,10 +250,10 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_tables, (size_t)LTOMPC_TABLE_ROWS * n_table);
   rc |= h->dalloc(&W.X, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.C, 8 * N * Bp), rc |= h->dalloc(&W.U, 2 * N * Bp);
   rc |= h->dalloc(&W.L1, 8 * N * Bp), rc |= h->dalloc(&W.L2, 8 * N * Bp);
-  rc |= h->dalloc(&W.T, ni * N * Bp), rc |= h->dalloc(&W.NU, ni * N * Bp);
+  rc |= h->dalloc(&W.T, (ni + NNL) * N * Bp), rc |= h->dalloc(&W.NU, ni * N * Bp);  // T: slacks + elastic variables (soft_rho)
   rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.dC, 8 * N * Bp), rc |= h->dalloc(&W.dU, 2 * N * Bp);
   rc |= h->dalloc(&W.nL1, 8 * N * Bp), rc |= h->dalloc(&W.nL2, 8 * N * Bp);
-  rc |= h->dalloc(&W.dT, ni * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
+  rc |= h->dalloc(&W.dT, (ni + NNL) * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
   rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp + 64), rc |=  // (+64: k_riccati8 fetches one field past the last block)
   h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
   rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp);

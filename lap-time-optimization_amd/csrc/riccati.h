@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
     smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
   }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3;  // multipliers counted (last slot has no nl constraints)
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (last slot has no nl constraints)
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
@@ -312,7 +312,7 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   double smult = 0.0, obj;
   obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
@@ -686,7 +686,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   double smult = 0.0, obj;
   obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3;
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);

@@ -418,6 +418,8 @@ typedef struct {
   int N;
   double *x, *c, *u, *l1, *l2; /* (N+1)*8, N*8, N*2, N*8, N*8 */
   double *t, *nu;              /* N*MAXI */
+  double *e;                   /* N*NNL: elastic variables of the softened track constraints (soft_rho > 0) */
+  double rho;
 } iterate_t;
 
 static iterate_t it_alloc(int N) {
@@ -430,16 +432,18 @@ static iterate_t it_alloc(int N) {
   it.l2 = calloc((size_t)N * NX, sizeof(double));
   it.t = calloc((size_t)N * MAXI, sizeof(double));
   it.nu = calloc((size_t)N * MAXI, sizeof(double));
+  it.e = calloc((size_t)N * NNL, sizeof(double));
+  it.rho = 0;
   return it;
 }
 static void it_free(iterate_t* it) {
-  free(it->x), free(it->c), free(it->u), free(it->l1), free(it->l2), free(it->t), free(it->nu);
+  free(it->x), free(it->c), free(it->u), free(it->l1), free(it->l2), free(it->t), free(it->nu), free(it->e);
 }
 
 /* inequality values of slot k (u_k, c_k, x_{k+1}); order: u bounds, c bounds, x+ bounds, gL, gR.
  * nl constraints exist at nodes 1..N-1 only (node 0 is fixed data, node N is not checked by do_mpc). */
 static void slot_ineq(const ltompc_params* p, const tables_t* T, const bounds_t* bd, int N, int k,
-                      const double* u, const double* c, const double* xp, double* h, int* active) {
+                      const double* u, const double* c, const double* xp, const double* e, double* h, int* active) {
   int m = 0;
   for (int i = 0; i < bd->n_ub; i++, m++) h[m] = bound_h(bd->ub_sgn[i], bd->ub_val[i], u[bd->ub_idx[i]]), active[m] = 1;
   for (int i = 0; i < bd->n_xb; i++, m++) h[m] = bound_h(bd->xb_sgn[i], bd->xb_val[i], c[bd->xb_idx[i]]), active[m] = 1;
@@ -447,7 +451,7 @@ static void slot_ineq(const ltompc_params* p, const tables_t* T, const bounds_t*
   int nl = (k + 1 <= N - 1);
   double g[NNL] = {-1, -1, -1};
   if (nl) cons_val(p, T, xp, g);
-  for (int q = 0; q < NNL; q++) h[m] = g[q], active[m++] = nl;
+  for (int q = 0; q < NNL; q++) h[m] = g[q] - (e && nl ? e[q] : 0.0), active[m++] = nl; /* soft: h = g - e */
 }
 
 /* filter-line-search measures at a (trial) point: theta = ||c||_1 + ||h + t||_1, cost, sum ln t */
@@ -470,12 +474,16 @@ static void eval_measures(const ltompc_params* p, const ltompc_options* o, const
     for (int i = 0; i < NU; i++) co += p->r_du[i] * (u[i] - v[i]) * (u[i] - v[i]);
     double h[MAXI];
     int act[MAXI];
-    slot_ineq(p, T, bd, N, k, u, c, xp, h, act);
+    slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, h, act);
     for (int m = 0; m < bd->ni; m++)
       if (act[m]) {
         double t = it->t[k * MAXI + m];
         th += fabs(h[m] + t);
         sl += log(t);
+        if (it->rho > 0 && m >= bd->ni - NNL) {
+          double e = it->e[k * NNL + m - (bd->ni - NNL)];
+          sl += log(e), co += it->rho * e;
+        }
       }
   }
   *theta = th, *cost = co, *sumlog = sl;
@@ -531,7 +539,7 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
     for (int b = 0; b < NX; b++) L->Hxp[a * 8 + b] += cj.h[hidx(a, b)];
   }
   L->Du[0] = L->Du[1] = 0, L->gub[0] = L->gub[1] = 0, L->du_dual[0] = L->du_dual[1] = 0;
-  slot_ineq(p, T, bd, N, k, u, c, xp, L->h, L->act);
+  slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, L->h, L->act);
   /* barrier contributions: Sigma = nu/t on the Hessian, sigma = (mu + nu (h + t))/t on the gradient */
   int m = 0;
   for (int i = 0; i < bd->n_ub; i++, m++) {
@@ -556,6 +564,11 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
     for (int q = 0; q < NNL; q++) {
       int mm = m + q;
       double Sg = nu[mm] / t[mm], sg = (mu + nu[mm] * (L->h[mm] + t[mm])) / t[mm];
+      if (it->rho > 0) { /* softened: g - e + t = 0, e >= 0 with multiplier z = rho - nu */
+        double e = it->e[k * NNL + q], z = it->rho - nu[mm];
+        Sg = 1.0 / (t[mm] / nu[mm] + e / z);
+        sg = (nu[mm] + Sg * g[q].v) + mu * (Sg * (1.0 / nu[mm] - 1.0 / z));
+      }
       for (int a = 0; a < NX; a++) {
         L->gnl[q][a] = g[q].g[a];
         L->gxp[a] += sg * g[q].g[a];
@@ -598,6 +611,9 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   (Tl.eps_mu = 0.0, Tl.eps_s = (o->smooth_scale > 0 || o->smooth_eps_min > 0) ? fmax(o->smooth_eps_min, o->smooth_scale * (mu_)) : 0.0)
   SET_SMOOTHING(o->mu_init);
   iterate_t it = it_alloc(N), tr = it_alloc(N);
+  const double rho = o->soft_rho;
+  it.rho = tr.rho = rho;
+  double* de = calloc((size_t)N * NNL, sizeof(double));
   slot_lin* L = malloc(sizeof(slot_lin) * (size_t)N);
   stage_ws* W = malloc(sizeof(stage_ws) * (size_t)N);
   double* dx = calloc((size_t)(N + 1) * NX, sizeof(double));
@@ -635,11 +651,17 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   for (int k = 0; k < N; k++) {
     double h[MAXI];
     int act[MAXI];
-    slot_ineq(p, T, &bd, N, k, it.u + k * NU, it.c + k * NX, it.x + (k + 1) * NX, h, act);
+    slot_ineq(p, T, &bd, N, k, it.u + k * NU, it.c + k * NX, it.x + (k + 1) * NX, NULL, h, act);
     for (int m = 0; m < ni; m++) {
+      int soft = rho > 0 && m >= ni - NNL;
+      if (soft) {
+        double e = fmax(h[m] + o->bound_push, mu / rho);
+        it.e[k * NNL + m - (ni - NNL)] = e, h[m] -= e;
+      }
       double t = -h[m] > o->bound_push ? -h[m] : o->bound_push;
       it.t[k * MAXI + m] = t;
       it.nu[k * MAXI + m] = getenv("ORACLE_NU1") ? 1.0 : mu / t;
+      if (soft) it.nu[k * MAXI + m] = fmin(mu / t, 0.5 * rho);
     }
   }
 
@@ -670,6 +692,8 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       const double *l1 = it.l1 + k * NX, *l2 = it.l2 + k * NX;
       const double* v = k ? it.u + (k - 1) * NU : uprev;
       obj += L[k].cost;
+      if (rho > 0 && L[k].act[ni - 1])
+        for (int q = 0; q < NNL; q++) obj += rho * it.e[k * NNL + q];
       for (int a = 0; a < NX; a++) {
         double rcx = L[k].dc_dual[a] + 4.5 * l2[a];
         double rxp = L[k].dxp_dual[a] - 0.5 * l1[a];
@@ -696,6 +720,11 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           rc_mu = fmax(rc_mu, fabs(t * nu - mu));
           rc_0 = fmax(rc_0, fabs(t * nu));
           sum_mult += fabs(nu), n_mult++;
+          if (rho > 0 && m >= ni - NNL) {
+            double ez = it.e[k * NNL + m - (ni - NNL)] * (rho - nu);
+            rc_mu = fmax(rc_mu, fabs(ez - mu)), rc_0 = fmax(rc_0, fabs(ez));
+            sum_mult += fabs(rho - nu), n_mult++;
+          }
         }
     }
     double s_d = fmax(o->s_max, sum_mult / n_mult) / o->s_max;
@@ -715,7 +744,10 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       double rcm = 0;
       for (int k = 0; k < N; k++)
         for (int m = 0; m < ni; m++)
-          if (L[k].act[m]) rcm = fmax(rcm, fabs(it.t[k * MAXI + m] * it.nu[k * MAXI + m] - mu));
+          if (L[k].act[m]) {
+            rcm = fmax(rcm, fabs(it.t[k * MAXI + m] * it.nu[k * MAXI + m] - mu));
+            if (rho > 0 && m >= ni - NNL) rcm = fmax(rcm, fabs(it.e[k * NNL + m - (ni - NNL)] * (rho - it.nu[k * MAXI + m]) - mu));
+          }
       Emu = fmax(Emu, rcm / s_d);
     }
     if (mu_changed) {
@@ -996,6 +1028,18 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         double t = it.t[k * MAXI + m], nu = it.nu[k * MAXI + m];
         double dtt = -(L[k].h[m] + t) - gd;
         double dn = (mu - nu * dtt) / t - nu;
+        if (rho > 0 && m >= ni - NNL) {
+          int q = m - (ni - NNL);
+          double e = it.e[k * NNL + q], z = rho - nu;
+          double Sg = 1.0 / (t / nu + e / z);
+          dn = Sg * (gd + (L[k].h[m] + e) + mu / nu - mu / z);
+          dtt = mu / nu - t - (t / nu) * dn;
+          double dee = mu / z - e + (e / z) * dn;
+          de[k * NNL + q] = dee;
+          if (dee < 0) a_pri = fmin(a_pri, -tau * e / dee);
+          if (dn > 0) a_dua = fmin(a_dua, tau * z / dn);
+          gphi_d += rho * dee - mu * dee / e;
+        }
         dt[k * MAXI + m] = dtt, dnu[k * MAXI + m] = dn;
         if (dtt < 0 && -tau * t / dtt < a_pri && getenv("ORACLE_TRACE2")) fprintf(stderr, "     limit k=%d m=%d t=%.3e dt=%.3e h=%.3e gd=%.3e\n", k, m, t, dtt, L[k].h[m], gd);
         if (dtt < 0) a_pri = fmin(a_pri, -tau * t / dtt);
@@ -1022,6 +1066,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         for (int i = 0; i < NX; i++) tr.c[k * NX + i] = it.c[k * NX + i] + alpha * dc[k * NX + i];
         for (int i = 0; i < NU; i++) tr.u[k * NU + i] = it.u[k * NU + i] + alpha * du[k * NU + i];
         for (int m = 0; m < ni; m++) tr.t[k * MAXI + m] = it.t[k * MAXI + m] + alpha * dt[k * MAXI + m];
+        for (int q = 0; q < NNL; q++) tr.e[k * NNL + q] = it.e[k * NNL + q] + alpha * de[k * NNL + q];
       }
       double th, co, sl;
       eval_measures(p, o, T, &bd, &tr, uprev, &th, &co, &sl);
@@ -1078,6 +1123,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         /* IPOPT eq. (16): keep nu within [mu/(kS t), kS mu/t], kS = 1e10 */
         double lo = mu / (1e10 * t), hi = 1e10 * mu / t;
         it.t[k * MAXI + m] = t, it.nu[k * MAXI + m] = nu < lo ? lo : (nu > hi ? hi : nu);
+        if (rho > 0 && m >= ni - NNL) it.e[k * NNL + m - (ni - NNL)] += alpha * de[k * NNL + m - (ni - NNL)];
       }
     }
   }
@@ -1092,7 +1138,7 @@ done:
       for (int m = 0; m < ni; m++) Tout[k * ni + m] = it.t[k * MAXI + m], NUout[k * ni + m] = it.nu[k * MAXI + m];
   st->status = status, st->iters = iter, st->kkt = E0, st->obj = obj, st->mu = mu;
   it_free(&it), it_free(&tr);
-  free(L), free(W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu);
+  free(L), free(W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu), free(de);
   return 0;
 }
 

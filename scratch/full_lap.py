@@ -5,6 +5,7 @@ T = ltompc.build_tables()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 x = ltompc.X0_REFERENCE[None].copy()
 o = ltompc.default_options(); o.max_iter = 300
+o.soft_rho = float(os.environ.get('SOFT_RHO', '0'))
 m = ltompc.BatchedMPC(T, N, 1, options=o); m.set_initial_guess(x)
 s_end = T.s_max - 0.1 * N * 25.0  # horizon look-ahead at v_max
 t_solve, ticks, fails, iters = 0.0, 0, 0, []

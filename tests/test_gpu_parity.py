@@ -419,3 +419,48 @@ def test_profiling_api(pkg, tables, gpu_lib):
     assert tm["launches_by_kernel"]["riccati1"] > 0 and tm["launches_by_kernel"]["step1"] > 0  # narrow launches (B <= 512)
     m.set_profiling(False)
     m.close()
+
+
+def test_soft_track_constraints_match_oracle(pkg, tables, orc, gpu_lib):
+    """options.soft_rho (do_mpc's soft_constraint / penalty_term_cons on the track constraints): the HIP path against
+    the oracle with the same option, both evaluation kernels, cold start + 2 warm ticks.  The batch contains states in
+    the chicane at s ~ 400 m where the hard-constrained NLP is infeasible."""
+    B, N = 48, 20
+    x0 = pkg.sample_x0(tables, B, seed=5)
+    x0[:8] = np.concatenate([_midtrack_x0(tables, s) for s in np.linspace(396.0, 410.0, 8)])
+    oo = orc.default_options(); oo.soft_rho = 100.0
+    oracle = orc.Oracle(tables.packed(), options=oo)
+    for mode in (2, 1):
+        o = pkg.default_options(); o.soft_rho, o.latency_mode = 100.0, mode
+        mpc = pkg.BatchedMPC(tables, N, B, options=o)
+        mpc.set_initial_guess(x0)
+        x, ref, uprev = x0.copy(), None, np.zeros((B, 2))
+        for tick in range(3):
+            u0 = mpc.make_step(x)
+            ref = oracle.solve(x, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
+            both = (mpc.status == 0) & (ref["status"] == 0)
+            assert both.mean() > 0.9, (mode, tick, both.mean())
+            assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, (mode, tick)
+            assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9, (mode, tick)
+            assert np.abs(mpc.stats()["obj"] - ref["obj"])[both].max() < 1e-6 * max(1.0, np.abs(ref["obj"][both]).max())
+            x, uprev = oracle.plant_step(x, ref["u0"]), ref["u0"]
+        mpc.close()
+
+
+def test_soft_track_constraints_keep_the_closed_loop_alive_through_the_chicane(pkg, tables, gpu_lib):
+    """With hard track constraints (the reference's formulation) the closed loop from the reference's x0 stops
+    converging at s ~ 405 m, where the track is narrower than the car's footprint; with soft_rho = 100 every tick
+    between s = 380 m and s = 440 m converges and the car stays within 0.2 m of the band."""
+    o = pkg.default_options(); o.soft_rho, o.max_iter = 100.0, 300
+    x = _midtrack_x0(tables, 380.0); x[0, 3] = 9.0
+    mpc = pkg.BatchedMPC(tables, 40, 1, options=o)
+    mpc.set_initial_guess(x)
+    ticks = 0
+    while x[0, 0] < 440.0 and ticks < 120:
+        u = mpc.make_step(x)
+        assert mpc.status[0] in (0, 1), (ticks, x[0, 0], mpc.status[0])
+        x = mpc.plant_step(x, u); ticks += 1
+        nl, nr = np.interp(x[0, 0], tables.s_arc, tables.n_left), np.interp(x[0, 0], tables.s_arc, tables.n_right)
+        assert -nr - 0.2 - 1.15 < x[0, 1] < nl + 0.2 + 1.15, (ticks, x[0])  # centre of gravity; half width of the car 1.15 m
+    assert x[0, 0] >= 440.0
+    mpc.close()
