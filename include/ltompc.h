@@ -83,10 +83,11 @@ typedef struct ltompc_options {
   /* Softened track constraints (do_mpc: set_nl_cons(..., soft_constraint=True, penalty_term_cons=soft_rho)).
    * 0 = hard constraints gL, gR <= 0 as in the reference (controller.py:69-70).  > 0: every track constraint of every
    * node gets an elastic variable e >= 0 (g - e <= 0) that costs soft_rho * e (exact L1 penalty: the solution is the
-   * hard-constrained one wherever that exists and soft_rho exceeds its multipliers, and a least-violation one where
-   * the track is narrower than the car, e.g. the chicane of buckmore at s = 405 m where the hard problem is
-   * infeasible and the reference's closed loop stops).  The elastic variables are eliminated with the slacks:
-   * same stage-QP sizes, same kernels, three more planes per interval. */
+   * hard-constrained one wherever that exists and soft_rho exceeds its multipliers, a least-violation one otherwise).
+   * It also is what keeps the closed loop going: from some states the lap reaches, the hard-constrained solve stalls
+   * (no restoration phase here) or has no feasible point at all, and every later tick inherits the failure; with
+   * soft_rho = 100 all 769 ticks of the buckmore lap converge.  The elastic variables are eliminated
+   * with the slacks: same stage-QP sizes, same kernels, three more planes per interval. */
   double soft_rho;        /* 0 */
   int max_iter;           /* controller.py:18 says 1000 */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */

@@ -111,7 +111,11 @@ class Controller:
     """src/mpc/controller.py:9-34: NLP weights, bounds and IPOPT settings; builds the device solver."""
 
     def __init__(self, model: VehicleModel, control_costs, n_horizon: int = 10, t_step: float = 0.1, n_robust: int = 0,
-                 batch: int = 1, device: int = 0, options=None):
+                 batch: int = 1, device: int = 0, options=None, soft_constraint: bool = False,
+                 penalty_term_cons: float = 100.0):
+        """soft_constraint / penalty_term_cons: the keyword arguments of do_mpc's set_nl_cons, applied to the two track
+        constraints of controller.py:69-70 (the reference passes neither: hard constraints, with which the closed loop
+        stops converging part-way round buckmore; see options.soft_rho in include/ltompc.h and DESIGN.md §6)."""
         control_costs = np.asarray(control_costs, dtype=np.float64)
         assert control_costs.shape == (2, 1)  # controller.py:38
         if n_robust != 0:
@@ -123,6 +127,10 @@ class Controller:
         p.q_n, p.q_mu, p.q_B = 0.5, 3.0, 1e-2  # controller.py:29
         o = options or _lib.default_options()
         o.t_step = t_step
+        if soft_constraint:
+            if not penalty_term_cons > 0:
+                raise ValueError("penalty_term_cons must be positive")
+            o.soft_rho = float(penalty_term_cons)
         self.solver = BatchedMPC(model.track.tables, n_horizon=n_horizon, batch=batch, params=p, options=o, device=device)
         self.mpc = _MPC(self.solver)
 

@@ -129,9 +129,14 @@ def inequalities(X, C, U, tab, eps):
     return torch.cat([torch.stack(cols, dim=-1), g], dim=-1)
 
 
-def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 0.1):
+def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 0.1, rho: float = 0.0):
     """Residuals of the KKT conditions of the NLP at solution `sol` (dict with X, C, U, L1, L2, NU of instance b):
-    returns dict(stationarity, equality, ineq_violation, complementarity, min_multiplier, objective)."""
+    returns dict(stationarity, equality, ineq_violation, complementarity, min_multiplier, objective).
+
+    rho > 0: the track constraints are softened with an exact L1 penalty, min J + rho sum(e), g - e <= 0, e >= 0.  With
+    the elastic variables at their optimum e = max(g, 0) the conditions are: stationarity in (x, c, u) as before,
+    0 <= nu <= rho, nu * max(-g, 0) = 0 and (rho - nu) * max(g, 0) = 0; `ineq_violation` then covers the bounds only,
+    the track violation is returned as `soft_violation` and the objective includes the penalty."""
     X = torch.tensor(sol["X"][b]).clone()
     X[0] = torch.as_tensor(x0)
     Xf = X[1:].clone().requires_grad_(True)
@@ -148,6 +153,15 @@ def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 
     gX, gC, gU = torch.autograd.grad(Lag, [Xf, C, U])
     Hd = H.detach().clone()
     Hd[N - 1, -3:] = -1.0
+    if rho > 0:
+        Ht, NUt = Hd[:, -3:], NU[:, -3:]
+        comp = torch.maximum((NUt * torch.clamp(-Ht, min=0.0)).abs().max(), ((rho - NUt) * torch.clamp(Ht, min=0.0)).abs().max())
+        comp = torch.maximum(comp, (NU[:, :-3] * Hd[:, :-3]).abs().max())
+        return dict(stationarity=float(max(gX.abs().max(), gC.abs().max(), gU.abs().max())),
+                    equality=float(max(G1.detach().abs().max(), G2.detach().abs().max())),
+                    ineq_violation=float(Hd[:, :-3].max()), soft_violation=float(torch.clamp(Ht, min=0.0).max()),
+                    complementarity=float(comp), min_multiplier=float(NU.min()), max_track_multiplier=float(NUt.max()),
+                    objective=float(J.detach() + rho * torch.clamp(Ht, min=0.0).sum()))
     return dict(stationarity=float(max(gX.abs().max(), gC.abs().max(), gU.abs().max())),
                 equality=float(max(G1.detach().abs().max(), G2.detach().abs().max())),
                 ineq_violation=float(Hd.max()), complementarity=float((NU * Hd).abs().max()),

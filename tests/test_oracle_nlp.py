@@ -110,3 +110,57 @@ def test_edge_horizons(oracle):
     assert r["status"][0] == 0 and r["X"].shape == (1, 3, 8)
     r = oracle.solve(np.repeat(X0, 3, axis=0), 5, nthreads=3)
     assert np.abs(r["u0"] - r["u0"][0]).max() == 0.0  # identical instances -> identical bits, thread-count independent
+
+
+def _midtrack_x0(tables, s):
+    nl, nr = np.interp(s, tables.s_arc, tables.n_left), np.interp(s, tables.s_arc, tables.n_right)
+    vref, kap = np.interp(s, tables.s_arc, tables.v_ref), np.interp(s, tables.s_kappa, tables.kappa)
+    vx = 0.6 * vref
+    return np.array([[s, 0.5 * (nl - nr), 0.0, vx, 0.0, kap * vx, np.arctan(3.0 * kap), 0.1]])
+
+
+def test_soft_track_constraints_are_an_exact_penalty(orc, tables):
+    """options.soft_rho (do_mpc: soft_constraint=True, penalty_term_cons): where the hard-constrained NLP is feasible
+    and the penalty exceeds its multipliers, the softened NLP has the same solution."""
+    hard = orc.Oracle(tables.packed())
+    o = orc.default_options(); o.soft_rho = 100.0
+    soft = orc.Oracle(tables.packed(), options=o)
+    x0 = np.vstack([X0, _midtrack_x0(tables, 150.0), _midtrack_x0(tables, 600.0)])
+    for N in (10, 20):
+        a, b = hard.solve(x0, N, nthreads=3), soft.solve(x0, N, nthreads=3)
+        assert np.all(a["status"] == 0) and np.all(b["status"] == 0)
+        assert a["NU"][:, :, -3:].max() < 100.0  # the premise: multipliers of the hard problem below the penalty
+        assert np.abs(a["u0"] - b["u0"]).max() < 1e-6
+        assert np.abs(a["X"] - b["X"]).max() < 1e-5
+        assert b["obj"] == pytest.approx(a["obj"], rel=1e-8, abs=1e-6)  # (the penalty adds rho e ~ mu_final per constraint)
+
+
+# Closed-loop states (reference x0, hard constraints, oracle in the loop; scratch/oracle_lap.py) at which the
+# hard-constrained solve stops with status STALLED, for N = 20 and N = 40: (x, u_prev)
+STALL_STATES = {
+    20: ([226.623754, -0.545036120, -0.0112268024, 8.52329373, 0.122918012, 0.161888169, 0.0837443810, 0.371730909],
+         [0.78837973, -0.00572868]),
+    40: ([271.551631, -3.15996996e-03, -0.138116402, 9.84560464, 0.483360380, 0.717172238, 0.338696158, -0.336634617],
+         [1.17640462, -0.99999992]),
+}
+
+
+@pytest.mark.parametrize("N", [20, 40])
+def test_soft_track_constraints_solve_where_the_hard_solve_stalls(orc, tables, N):
+    """The states at which the closed loop with the reference's hard track constraints stops converging (no
+    restoration phase here).  The softened NLP converges from them, to a point that satisfies its KKT
+    conditions as evaluated by the independent torch implementation: for N = 20 without any violation (a KKT point of
+    the hard NLP, multipliers 4 << rho: the stall was the solver's), for N = 40 with 0.1 mm of overlap at nu = rho."""
+    x, up = (np.array([v]) for v in STALL_STATES[N])
+    assert orc.Oracle(tables.packed()).solve(x, N, up)["status"][0] == 4
+    rho = 100.0
+    o = orc.default_options(); o.soft_rho = rho
+    soft = orc.Oracle(tables.packed(), options=o)
+    r = soft.solve(x, N, up)
+    assert r["status"][0] == 0
+    k = R.kkt_residuals(r, x[0], up[0], tables, soft.o.smooth_eps_min, 0, rho=rho)
+    assert k["stationarity"] < 1e-6 and k["equality"] < 1e-7 and k["ineq_violation"] < 1e-7, k
+    assert k["complementarity"] < 1e-6 and k["min_multiplier"] >= 0.0 and k["max_track_multiplier"] <= rho, k
+    assert k["soft_violation"] < 1e-3, k
+    assert (k["soft_violation"] == 0.0) == (N == 20)
+    assert k["objective"] == pytest.approx(r["obj"][0], rel=1e-8, abs=1e-6)
