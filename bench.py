@@ -221,6 +221,28 @@ def main():
         extras["closed_loop_n60"] = {"ticks": 300, "simulated_s": 30.0, "solve_wall_s": t60, "real_time_factor": 30.0 / t60,
                                      "s_reached_m": float(x60[0, 0]), "non_converged_ticks": bad60, "ip_iters_mean": it60 / 300.0}
         m60.close()
+        # ... and the whole lap with the track constraints softened (options.soft_rho = 100, do_mpc's soft_constraint /
+        # penalty_term_cons; an extension: the reference's hard constraints stop the loop part-way): until the horizon
+        # reaches the end of the tables
+        o60.soft_rho = 100.0
+        m60 = ltompc.BatchedMPC(tables, n_horizon=60, batch=1, options=o60, device=local_rank)
+        m60.set_stream(stream.cuda_stream)
+        x60 = ltompc.X0_REFERENCE[None].copy()
+        m60.set_initial_guess(x60)
+        s_end = tables.s_max - 0.1 * 60 * 25.0
+        t60, bad60, it60, n60 = 0.0, 0, 0, 0
+        while x60[0, 0] < s_end and n60 < 1500:
+            tb = time.perf_counter()
+            u60 = m60.make_step(x60)
+            t60 += time.perf_counter() - tb
+            bad60 += int(m60.status[0] != 0)
+            it60 += int(m60.iters[0])
+            x60 = m60.plant_step(x60, u60)
+            n60 += 1
+        extras["closed_loop_lap_soft_n60"] = {"options": {"soft_rho": 100.0}, "ticks": n60, "simulated_s": 0.1 * n60, "solve_wall_s": t60,
+                                              "real_time_factor": 0.1 * n60 / t60, "s_reached_m": float(x60[0, 0]),
+                                              "s_target_m": float(s_end), "non_converged_ticks": bad60, "ip_iters_mean": it60 / max(n60, 1)}
+        m60.close()
 
     # ---- same workload with the warm start tuned for MPC (extension, not the reference's solver settings): previous
     #      solution shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same
