@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--max-iter", type=int, default=150, help="interior-point iteration budget per solve")
+    ap.add_argument("--soft-rho", type=float, default=0.0, help="options.soft_rho for the timed run and the CPU baseline (extension: "
+                    "softened track constraints; 0 = the reference's hard constraints)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="instances solved by the CPU oracle for cpu_baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
@@ -87,7 +89,7 @@ def main():
     tables = ltompc.build_tables()  # buckmore / MX-5 / curvature race line (the only one the reference MPC runs on)
     B, N = args.batch, args.horizon
     opts = ltompc.default_options()
-    opts.max_iter = args.max_iter
+    opts.max_iter, opts.soft_rho = args.max_iter, args.soft_rho
     mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
     stream = torch.cuda.current_stream(dev)
     mpc.set_stream(stream.cuda_stream)
@@ -281,7 +283,7 @@ def main():
         nthreads = min(ncores, 16)
         S = min(args.cpu_sample, B)
         oo = orc.default_options()
-        oo.max_iter = args.max_iter
+        oo.max_iter, oo.soft_rho = args.max_iter, args.soft_rho
         O = orc.Oracle(tables.packed(), options=oo)
         xs = x0_host[:S]
         r = O.solve(xs, N, nthreads=nthreads)  # cold start, untimed (creates the warm start)
@@ -309,7 +311,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"batch={B} per GPU x {world} GPU, horizon N={N}, closed-loop warm ticks "
                                    f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
-                       "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol,
+                       "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "solved_frac_last_tick": n_solved_last / (B * world),
             "ip_iters_mean_last_tick": iters_last / (B * world),

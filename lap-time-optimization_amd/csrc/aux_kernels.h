@@ -53,11 +53,16 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   double gv[3] = {-1.0, -1.0, -1.0};
   if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
   for (int q = 0; q < 3; q++) {
-    double hq = gv[q], e = 0.0;
-    if (K.o.soft_rho > 0.0 && k + 1 <= N - 1) e = fmax(gv[q] + K.o.bound_push, mu / K.o.soft_rho), hq -= e;  // g - e + t = 0
-    const double t = -hq > K.o.bound_push ? -hq : K.o.bound_push;
-    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e;
-    PL(W.NU, m + q, k, N) = (K.o.soft_rho > 0.0) ? fmin(mu / t, 0.5 * K.o.soft_rho) : mu / t;  // soft: 0 < nu < rho
+    double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push, e = 0.0;
+    if (K.o.soft_rho > 0.0) {
+      // softened: slack and multiplier as for the hard constraint (a violated constraint starts as an infeasibility of
+      // g - e + t = 0 that the Newton steps remove, not as a large elastic variable with nu ~ rho that the barrier lets
+      // go of only slowly); the elastic variable on the central path of its own pair, e (rho - nu) = mu.
+      // t >= 2 mu / rho keeps nu <= rho / 2.
+      t = fmax(t, 2.0 * mu / K.o.soft_rho);
+      e = mu / (K.o.soft_rho - mu / t);
+    }
+    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;
   }
   if (k == 0) {
     double* st = W.st;

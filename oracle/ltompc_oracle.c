@@ -567,7 +567,9 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
       if (it->rho > 0) { /* softened: g - e + t = 0, e >= 0 with multiplier z = rho - nu */
         double e = it->e[k * NNL + q], z = it->rho - nu[mm];
         Sg = 1.0 / (t[mm] / nu[mm] + e / z);
-        sg = (nu[mm] + Sg * g[q].v) + mu * (Sg * (1.0 / nu[mm] - 1.0 / z));
+        /* (the constraint value h + e of slot_ineq, not the jet's: the step recovery below must see the SAME number,
+         *  a difference of one ulp of the O(1) terms of g is amplified by Sg ~ nu / t ~ 1e9 into the dual residual) */
+        sg = (nu[mm] + Sg * (L->h[mm] + e)) + mu * (Sg * (1.0 / nu[mm] - 1.0 / z));
       }
       for (int a = 0; a < NX; a++) {
         L->gnl[q][a] = g[q].g[a];
@@ -653,15 +655,18 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     int act[MAXI];
     slot_ineq(p, T, &bd, N, k, it.u + k * NU, it.c + k * NX, it.x + (k + 1) * NX, NULL, h, act);
     for (int m = 0; m < ni; m++) {
-      int soft = rho > 0 && m >= ni - NNL;
-      if (soft) {
-        double e = fmax(h[m] + o->bound_push, mu / rho);
-        it.e[k * NNL + m - (ni - NNL)] = e, h[m] -= e;
+      if (rho > 0 && m >= ni - NNL) {
+        /* softened track constraint: slack and multiplier as for the hard one (t = max(-g, bound_push), nu = mu / t,
+         * so that a violated constraint starts as an INFEASIBILITY of g - e + t = 0 that the Newton steps remove, not
+         * as a large elastic variable with nu ~ rho that the barrier lets go of only slowly), the elastic variable
+         * on the central path of its own pair: e (rho - nu) = mu.  t >= 2 mu / rho keeps nu <= rho / 2. */
+        double t = fmax(fmax(-h[m], o->bound_push), 2 * mu / rho), nu = mu / t;
+        it.t[k * MAXI + m] = t, it.nu[k * MAXI + m] = nu, it.e[k * NNL + m - (ni - NNL)] = mu / (rho - nu);
+        continue;
       }
       double t = -h[m] > o->bound_push ? -h[m] : o->bound_push;
       it.t[k * MAXI + m] = t;
       it.nu[k * MAXI + m] = getenv("ORACLE_NU1") ? 1.0 : mu / t;
-      if (soft) it.nu[k * MAXI + m] = fmin(mu / t, 0.5 * rho);
     }
   }
 
