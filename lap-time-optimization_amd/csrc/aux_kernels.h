@@ -44,7 +44,7 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
   // (flat visitor, no nested by-reference lambdas: see d_expand)
-  const int m = for_each_bound(K.p, [&](int mm, int kind, int j, double sg, double val) {
+  const int m = for_each_bound<BoundsAny>(K.p, [&](int mm, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
     const double hv = sg * (xv - val);
     const double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;

@@ -123,7 +123,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
   S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0, S.csoft = 0.0;
   double hcd = 0.0, hxd = 0.0;  // additions to the diagonal entries Hc[i][i], Hx+[i][i]
   double lprod = 1.0;           // product of the slacks this lane owns (at most 6): one logarithm per lane
-  S.m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+  S.m_nl = for_each_bound<BoundsAny>(K.p, [&](int m, int kind, int j, double sg, double val) {
     if (j != i) return;
     const double xv = kind == 0 ? (j == 0 ? S.u[0] : S.u[1]) : (kind == 1 ? S.c_i : S.xp_i);
     const double hv = sg * (xv - val);
@@ -409,7 +409,7 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
     const double dv0 = k ? PL(W.dU, i, k - 1, N) : 0.0;
     gphid += 2.0 * K.p.r_du[i] * (ui - v0) * (dui - dv0);
   }
-  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+  for_each_bound<BoundsAny>(K.p, [&](int m, int kind, int j, double sg, double val) {
     if (j != i) return;
     const double xv = kind == 0 ? (j == 0 ? S.u[0] : S.u[1]) : (kind == 1 ? S.c_i : S.xp_i);
     const double dv = kind == 0 ? (j == 0 ? du[0] : du[1]) : (kind == 1 ? dc_i : dxp_i);

@@ -9,24 +9,41 @@ namespace ltompc {
 __device__ __forceinline__ double sym_get(const double* H, int i, int j) { return H[sidx(i, j)]; }
 
 
+// Which simple bounds exist, as a type.  BoundsAny reads it from the parameters at run time (one uniform branch per
+// possible bound: every bound becomes its own basic block, and the loads of its slack and multiplier cannot be moved
+// out of it - measured on k_eval: 46 serialised HBM round trips per wavefront).  BoundsFixed states it at compile time:
+// straight-line code, the loads are issued in batches.  BoundsRef is the pattern of the reference's controller
+// (controller.py:79-95: both input bounds; s >= 0, |mu| <= pi/2, vx >= 0, |delta| <= pi/4, |T| <= 1); a handle whose
+// parameters have exactly this pattern runs the kernels instantiated for it (same arithmetic, same bits).
+struct BoundsAny {
+  static constexpr bool fixed = false;
+  static constexpr unsigned ulb = 0, uub = 0, xlb = 0, xub = 0;
+};
+template <unsigned ULB, unsigned UUB, unsigned XLB, unsigned XUB>
+struct BoundsFixed {
+  static constexpr bool fixed = true;
+  static constexpr unsigned ulb = ULB, uub = UUB, xlb = XLB, xub = XUB;  // bit i: variable i has the bound
+};
+using BoundsRef = BoundsFixed<0x3, 0x3, 0xCD, 0xC4>;
+
 // Visits the inequalities of a slot in their storage order (input bounds, Radau-point bounds, node bounds; per
 // variable lower then upper, only the bounds that are set).  `f(m, kind, i, sg, val)` gets the running index m,
 // kind 0/1/2 = u / c / x+, and the variable index i as a value that is a compile-time constant after unrolling,
 // so that per-variable arrays stay in registers (a run-time index would force them into scratch memory).
-template <typename F>
+template <class BP, typename F>
 __device__ __forceinline__ int for_each_bound(const ltompc_params& p, F&& f) {
   int m = 0;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
-    if (p.u_lb[i] > -LTOMPC_NO_BOUND) f(m++, 0, i, -1.0, p.u_lb[i]);
-    if (p.u_ub[i] < LTOMPC_NO_BOUND) f(m++, 0, i, 1.0, p.u_ub[i]);
+    if (BP::fixed ? ((BP::ulb >> i) & 1u) != 0 : p.u_lb[i] > -LTOMPC_NO_BOUND) f(m++, 0, i, -1.0, p.u_lb[i]);
+    if (BP::fixed ? ((BP::uub >> i) & 1u) != 0 : p.u_ub[i] < LTOMPC_NO_BOUND) f(m++, 0, i, 1.0, p.u_ub[i]);
   }
 #pragma unroll
   for (int kind = 1; kind <= 2; kind++) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      if (p.x_lb[i] > -LTOMPC_NO_BOUND) f(m++, kind, i, -1.0, p.x_lb[i]);
-      if (p.x_ub[i] < LTOMPC_NO_BOUND) f(m++, kind, i, 1.0, p.x_ub[i]);
+      if (BP::fixed ? ((BP::xlb >> i) & 1u) != 0 : p.x_lb[i] > -LTOMPC_NO_BOUND) f(m++, kind, i, -1.0, p.x_lb[i]);
+      if (BP::fixed ? ((BP::xub >> i) & 1u) != 0 : p.x_ub[i] < LTOMPC_NO_BOUND) f(m++, kind, i, 1.0, p.x_ub[i]);
     }
   }
   return m;  // index of the first track constraint
@@ -87,7 +104,7 @@ struct Slot {
   bool nl;
 };
 
-template <bool WITH_DUAL>
+template <bool WITH_DUAL, class BP>
 __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
   const int N = W.N;
   const double hdt = K.o.t_step, rho = K.o.soft_rho;
@@ -129,7 +146,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
   S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
   double lprod = 1.0;  // sum of log t = log of products of 8 slacks (3 logarithms per slot, see d_linesearch)
-  const int m_nl = for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+  const int m_nl = for_each_bound<BP>(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double hv = sg * (xv - val);
     const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
@@ -343,6 +360,7 @@ __device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8
 
 
 // ------------------------------------------------------------------------------------------ k_eval
+template <class BP>
 __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
@@ -350,7 +368,7 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   const double hdt = K.o.t_step;
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   Slot S;
-  linearise_slot<true>(K, W, k, b, eps, S);
+  linearise_slot<true, BP>(K, W, k, b, eps, S);
   // ---- residual partials (IPOPT's E_mu ingredients) ----
   {
     double l1[8], l2[8], rd = 0.0, rp = 0.0, sm = 0.0;
@@ -435,24 +453,26 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
 }
 
+template <class BP>
 __global__ void __launch_bounds__(64) k_eval(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
-  d_eval(K, W, k, la.act[j]);
+  d_eval<BP>(K, W, k, la.act[j]);
 }
 
 
 // ------------------------------------------------------------------------------------------ k_expand
+template <class BP>
 __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
   const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
   Slot S;
-  linearise_slot<false>(K, W, k, b, eps, S);
+  linearise_slot<false, BP>(K, W, k, b, eps, S);
   M8Blocks M8;
   double Y[88], AB[88];
   condense_slot(K, S, M8, Y, AB);
@@ -519,7 +539,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   // (one flat visitor: an earlier version with a second, nested by-reference lambda produced run-to-run varying
   //  values of gphid for the last interval on ROCm 7.2 / gfx950, a code-generation problem that instrumenting stores
   //  made disappear; tests/test_gpu_parity.py::test_full_size_batch_properties guards against its return)
-  for_each_bound(K.p, [&](int m, int kind, int j, double sg, double val) {
+  for_each_bound<BP>(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
     const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
@@ -556,11 +576,12 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
 
+template <class BP>
 __global__ void __launch_bounds__(64) k_expand(Consts K, Work W, Launch la) {
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
-  d_expand(K, W, k, la.act[j]);
+  d_expand<BP>(K, W, k, la.act[j]);
 }
 
 }  // namespace ltompc

@@ -12,6 +12,7 @@ namespace ltompc {
 // for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
 // Filter measures (theta, cost, sum log t) of the step candidates l_begin..l_end of interval k of instance b;
 // candidate l >= 1 has alpha = a_pri * 2^-(l-1) (l = 0, the current point, is written by k_eval).
+template <class BP>
 __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, const int k, const int b, const int l_begin,
                                              const int l_end) {
   const int N = W.N;
@@ -57,7 +58,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
     for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
     // sum of log t as the log of products of 8 slacks (same grouping in linearise_slot): 3 logarithms instead of 23
     double sl = 0.0, pr = 1.0;
-    const int m = for_each_bound(K.p, [&](int mm, int kind, int jj, double sg, double val) {
+    const int m = for_each_bound<BP>(K.p, [&](int mm, int kind, int jj, double sg, double val) {
       const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
       const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
       th += fabs(sg * (xv - val) + t), pr *= t;
@@ -84,6 +85,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   }
 }
 
+template <class BP>
 __global__ void __launch_bounds__(64, 2) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
@@ -96,7 +98,7 @@ __global__ void __launch_bounds__(64, 2) k_linesearch(const Consts* __restrict__
   if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
   const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
   const int l = phase == 0 ? 1 : 2 + cand;
-  for (int j = j0; j < count; j += jw) d_linesearch(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
+  for (int j = j0; j < count; j += jw) d_linesearch<BP>(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
 }
 
 // ------------------------------------------------------------------------------------------ k_pick
@@ -280,6 +282,7 @@ __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, co
 // ------------------------------------------------------------------------------------------ k_step1
 // Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
 // and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
+template <class BP>
 __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {  // 320 = 8 candidates x 40 intervals in one pass
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
@@ -290,7 +293,7 @@ __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, co
   if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
   // all step candidates at once (the threads are there anyway; the wide path evaluates candidates 2.. only for the
   // instances that rejected the full step, with the same arithmetic)
-  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
+  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
   __syncthreads();
   if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
   __syncthreads();

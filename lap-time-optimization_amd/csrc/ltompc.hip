@@ -64,6 +64,7 @@ struct ltompc_solver {
   int launches_by_kernel[NKERN] = {};
   Consts* d_K = nullptr;  // device copies of K and W for the solver kernels
   Work* d_W = nullptr;
+  bool bounds_ref = false;  // the parameters have the reference's bound pattern: kernels instantiated for it (LTOMPC_BOUNDS=any: never)
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
@@ -228,6 +229,14 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
     h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
     if (ev) h->eval8 = std::string(ev) == "wave";
+    {
+      unsigned ulb = 0, uub = 0, xlb = 0, xub = 0;
+      for (int i = 0; i < 2; i++) ulb |= (params->u_lb[i] > -LTOMPC_NO_BOUND) << i, uub |= (params->u_ub[i] < LTOMPC_NO_BOUND) << i;
+      for (int i = 0; i < 8; i++) xlb |= (params->x_lb[i] > -LTOMPC_NO_BOUND) << i, xub |= (params->x_ub[i] < LTOMPC_NO_BOUND) << i;
+      const char* bp = getenv("LTOMPC_BOUNDS");  // any: the run-time pattern kernels (tests)
+      h->bounds_ref = ulb == BoundsRef::ulb && uub == BoundsRef::uub && xlb == BoundsRef::xlb && xub == BoundsRef::xub &&
+                      !(bp && std::string(bp) == "any");
+    }
     const char* s1 = getenv("LTOMPC_STEP1");
     if (s1) h->step1_width = atoi(s1);
     const char* t = getenv("LTOMPC_RIC1");
@@ -378,7 +387,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   int it = 0;
   for (;; it++) {
     const int np = la.n_pad;
-    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, k_eval, N * np, h->d_K, h->d_W, la)) return -1;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->bounds_ref ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
     } else {
@@ -391,17 +400,17 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, k_expand, N * np, h->K, h->W, la)) return -1;
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, h->bounds_ref ? k_expand<BoundsRef> : k_expand<BoundsAny>, N * np, h->K, h->W, la)) return -1;
     if (n_launch <= h->step1_width) {
       // one workgroup per instance does both line-search phases, the filter test and the update
       L.block_threads = 320;
-      if (L.run(7, k_step1, n_launch * 320, h->d_K, h->d_W, la)) return -1;
+      if (L.run(7, h->bounds_ref ? k_step1<BoundsRef> : k_step1<BoundsAny>, n_launch * 320, h->d_K, h->d_W, la)) return -1;
     } else {
-      if (L.run(3, k_linesearch, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
+      if (L.run(3, h->bounds_ref ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
       if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
       if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
         const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
-        if (L.run(3, k_linesearch, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
+        if (L.run(3, h->bounds_ref ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
         if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 1)) return -1;
       }
       if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;

@@ -236,6 +236,12 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     monkeypatch.delenv("LTOMPC_RIC1")
     monkeypatch.delenv("LTOMPC_STEP1")
     monkeypatch.delenv("LTOMPC_COMPACT")
+    # kernels instantiated for the reference's bound pattern vs the run-time pattern ones: same arithmetic, same bits
+    monkeypatch.setenv("LTOMPC_BOUNDS", "any")
+    u_any, s_any = run()
+    assert np.array_equal(u_any, u_ref) and np.array_equal(s_any["iters"][solved], s_ref["iters"][solved])
+    assert np.array_equal(s_any["kkt"][solved], s_ref["kkt"][solved])
+    monkeypatch.delenv("LTOMPC_BOUNDS")
     monkeypatch.setenv("LTOMPC_RICCATI", "serial")
     u_se, s_se = run()
     ok = (s_se["status"] == 0) & (s_ref["status"] == 0)
@@ -471,4 +477,22 @@ def test_soft_track_constraints_closed_loop_lap(pkg, tables, gpu_lib):
         worst = max(worst, x[0, 1] - sa + cw - nl, -x[0, 1] + sa + cw - nr)
     assert x[0, 0] >= s_end and 700 < ticks < 850, (ticks, x[0, 0])
     assert worst < 0.05, worst
+    mpc.close()
+
+
+def test_other_bound_patterns_use_the_generic_kernels(pkg, tables, orc, gpu_lib):
+    """Parameters whose simple bounds differ from the reference's pattern (here: no bound on vx, an upper bound on n)
+    run the kernels that read the pattern at run time; checked against the oracle with the same parameters."""
+    B, N = 24, 20
+    p = pkg.default_params(); p.x_lb[3] = -pkg.NO_BOUND; p.x_ub[1] = 50.0
+    po = orc.default_params(); po.x_lb[3] = -pkg.NO_BOUND; po.x_ub[1] = 50.0
+    oracle = orc.Oracle(tables.packed(), params=po)
+    x0 = pkg.sample_x0(tables, B, seed=13)
+    mpc = pkg.BatchedMPC(tables, N, B, params=p)
+    mpc.set_initial_guess(x0)
+    u0 = mpc.make_step(x0)
+    ref = oracle.solve(x0, N, nthreads=8)
+    both = (mpc.status == 0) & (ref["status"] == 0)
+    assert both.mean() > 0.9 and np.abs(u0 - ref["u0"])[both].max() < 1e-5
+    assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9
     mpc.close()
