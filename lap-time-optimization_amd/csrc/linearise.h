@@ -328,7 +328,8 @@ __device__ __forceinline__ void condense_column(const Consts& K, const Slot& S, 
   }
 }
 
-__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8Blocks& M, double* Y, double* AB) {
+// M8 = 4.5 I + 2 E2 E1 in block form, diagonal blocks inverted
+__device__ __forceinline__ bool factor_m8(const Slot& S, M8Blocks& M) {
   // M8(i, j) = 4.5 delta_ij + 2 sum_l E2(i, l) E1(l, j): l runs where row i of E2 and column j of E1 overlap
   double maa[9], mbb[9];
 #pragma unroll
@@ -348,7 +349,11 @@ __device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8
         else M.bc[(i - 3) * 2 + j - 6] = s;
       }
     }
-  const bool ok = inv33(maa, M.iaa) & inv33(mbb, M.ibb);
+  return inv33(maa, M.iaa) & inv33(mbb, M.ibb);
+}
+
+__device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8Blocks& M, double* Y, double* AB) {
+  const bool ok = factor_m8(S, M);
 #pragma unroll
   for (int q = 0; q < 88; q++) Y[q] = 0.0, AB[q] = 0.0;
   condense_column<0>(K, S, M, Y, AB), condense_column<1>(K, S, M, Y, AB), condense_column<2>(K, S, M, Y, AB);
@@ -369,6 +374,13 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   Slot S;
   linearise_slot<true, BP>(K, W, k, b, eps, S);
+  // ---- node block of x_{k+1}: complete after the linearisation, stored now so that its 52 registers are free during
+  //      the elimination (stores issued late also cost more than their bandwidth: on gfx9 a later scratch reload
+  //      has to wait for every store before it, vmcnt counts both)
+#pragma unroll
+  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k + 1, QP_NF) = S.Hxp[i];
+#pragma unroll
+  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
   // ---- residual partials (IPOPT's E_mu ingredients) ----
   {
     double l1[8], l2[8], rd = 0.0, rp = 0.0, sm = 0.0;
@@ -447,10 +459,6 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     if (i < 8) PG(W.QP, QP_q0 + i, k, QP_NF) = s0, PG(W.QP, QP_q1 + i, k, QP_NF) = s1;
     else PG(W.QP, QP_r0 + i - 8, k, QP_NF) = s0 + S.gub0[i - 8], PG(W.QP, QP_r1 + i - 8, k, QP_NF) = s1 + S.gub1[i - 8];
   }
-#pragma unroll
-  for (int i = 0; i < 36; i++) PG(W.QP, QP_Qx + i, k + 1, QP_NF) = S.Hxp[i];
-#pragma unroll
-  for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
 }
 
 template <class BP>
@@ -471,33 +479,51 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
   const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
+  // costate pi_{k+1} = P_{k+1} dx_{k+1} + Pxv_{k+1} du_k + p_{k+1}: needs nothing of the linearisation, so it comes
+  // first (its 60 words of the Riccati buffer are fetched in one batch while few registers are live; placed after the
+  // elimination the compiler issued them one at a time, 40 serialised round trips).  Only pi is kept across the
+  // elimination, the steps are fetched again afterwards.
+  double pi[8];
+  {
+    double dxp0[8], du0[2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) dxp0[i] = PL(W.dX, i, k + 1, N + 1);
+    du0[0] = PL(W.dU, 0, k, N), du0[1] = PL(W.dU, 1, k, N);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      double s = PG(W.RC, RC_pp + i, k + 1, RC_NF) + PG(W.RC, RC_Pxv + i * 2, k + 1, RC_NF) * du0[0] +
+                 PG(W.RC, RC_Pxv + i * 2 + 1, k + 1, RC_NF) * du0[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += PG(W.RC, RC_P + sidx(i, j), k + 1, RC_NF) * dxp0[j];
+      pi[i] = s;
+    }
+  }
   Slot S;
   linearise_slot<false, BP>(K, W, k, b, eps, S);
   M8Blocks M8;
-  double Y[88], AB[88];
-  condense_slot(K, S, M8, Y, AB);
+  factor_m8(S, M8);
   double dxk[8], dxp[8], du[2], dc[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) dxk[i] = PL(W.dX, i, k, N + 1), dxp[i] = PL(W.dX, i, k + 1, N + 1);
   du[0] = PL(W.dU, 0, k, N), du[1] = PL(W.dU, 1, k, N);
+  // dc_k from the eliminated equations directly, one solve with the actual right-hand side (k_eval needs the 11
+  // columns of [Ac | Bc | bc] for the projection of the Hessian, this kernel only their product with (dx, du, 1)):
+  //   M8 dc = 2 dx - h Bu du - G2 - 2 E2 w ,   w = 2 dx + h Bu du + G1        (see condense_column)
+  {
+    const double hdt = K.o.t_step;
+    double w[8], v[8];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    double s = Y[i * 11 + 10] + Y[i * 11 + 8] * du[0] + Y[i * 11 + 9] * du[1];
+    for (int l = 0; l < 8; l++) w[l] = 2.0 * dxk[l] + (l >= 6 ? hdt * du[l - 6] : 0.0) + S.G1[l];
 #pragma unroll
-    for (int j = gs_(i); j < 8; j++)  // row i of Ac: block upper triangular, its (delta, T) block is the identity
-      if (i < 6 || j == i) s += Y[i * 11 + j] * dxk[j];
-    dc[i] = s;
-    PL(W.dC, i, k, N) = s;
-  }
-  // costate pi_{k+1} = P_{k+1} dx_{k+1} + Pxv_{k+1} du_k + p_{k+1}
-  double pi[8];
+    for (int i = 0; i < 8; i++) {
+      double s = 2.0 * dxk[i] - (i >= 6 ? hdt * du[i - 6] : 0.0) - S.G2[i];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    double s = PG(W.RC, RC_pp + i, k + 1, RC_NF) + PG(W.RC, RC_Pxv + i * 2, k + 1, RC_NF) * du[0] +
-               PG(W.RC, RC_Pxv + i * 2 + 1, k + 1, RC_NF) * du[1];
+      for (int l = elo_(i); l <= ehi_(i); l++) s -= 2.0 * S.E2[i * 8 + l] * w[l];
+      v[i] = s;
+    }
+    m8_solve<7>(M8, v, dc);
 #pragma unroll
-    for (int j = 0; j < 8; j++) s += PG(W.RC, RC_P + sidx(i, j), k + 1, RC_NF) * dxp[j];
-    pi[i] = s;
+    for (int i = 0; i < 8; i++) PL(W.dC, i, k, N) = dc[i];
   }
   // new collocation multipliers:  M8^T l2 = -(Hc dc + gc) - 2 E1^T pi ;  l1 = 2 (E2^T l2 + pi)
   double v[8];
@@ -539,10 +565,25 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   // (one flat visitor: an earlier version with a second, nested by-reference lambda produced run-to-run varying
   //  values of gphid for the last interval on ROCm 7.2 / gfx950, a code-generation problem that instrumenting stores
   //  made disappear; tests/test_gpu_parity.py::test_full_size_batch_properties guards against its return)
+  // With a compile-time bound pattern the slacks and multipliers are fetched in one batch before the loop (on gfx9 a
+  // load that follows a store waits for the store as well, vmcnt counts both in order: interleaved with the stores
+  // of dT / dNU every bound cost a load AND a store round trip).  Run-time pattern: the index m is not a constant,
+  // an array indexed by it would live in scratch memory, so that path loads where it uses.
+  double tt[BP::fixed ? MAX_NI + 3 : 1], nn[BP::fixed ? MAX_NI : 1];
+  if (BP::fixed) {
+    const int m0 = for_each_bound<BP>(K.p, [&](int m, int, int, double, double) { tt[m] = PL(W.T, m, k, N), nn[m] = PL(W.NU, m, k, N); });
+    if (S.nl) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        tt[m0 + q] = PL(W.T, m0 + q, k, N), nn[m0 + q] = PL(W.NU, m0 + q, k, N);
+        tt[m0 + 3 + q] = K.o.soft_rho > 0.0 ? PL(W.T, m0 + 3 + q, k, N) : 0.0;
+      }
+    }
+  }
   for_each_bound<BP>(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
     const double dv = kind == 0 ? du[j] : (kind == 1 ? dc[j] : dxp[j]);
-    const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+    const double t = BP::fixed ? tt[m] : PL(W.T, m, k, N), nu = BP::fixed ? nn[m] : PL(W.NU, m, k, N), it = 1.0 / t;
     const double dtt = -(sg * (xv - val) + t) - sg * dv;
     const double dn = (mu - nu * dtt) * it - nu;
     PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn;
@@ -554,11 +595,11 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   for (int q = 0; q < 3; q++) {
     const int m = S.m_nl + q;
     if (S.nl) {
-      const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
+      const double t = BP::fixed ? tt[m] : PL(W.T, m, k, N), nu = BP::fixed ? nn[m] : PL(W.NU, m, k, N), it = 1.0 / t;
       const double gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
       if (K.o.soft_rho > 0.0) {
         double dtt, dn, dee;
-        track_soft_step(K.o.soft_rho, mu, tau, S.gv[q], gd, t, nu, PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        track_soft_step(K.o.soft_rho, mu, tau, S.gv[q], gd, t, nu, BP::fixed ? tt[m + 3] : PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
         PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
       } else {
         const double dtt = -(S.gv[q] + t) - gd;
