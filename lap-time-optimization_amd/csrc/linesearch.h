@@ -20,7 +20,13 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   double a_pri = 1.0;
-  for (int kk = 0; kk < N; kk++) a_pri = fmin(a_pri, PL(W.SP, SP_apri, kk, N));
+  for (int kk = 0; kk < N; kk += 8) {  // eight loads in flight per round trip (a plain loop waits for every single one)
+    double v8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v8[q] = PL(W.SP, SP_apri, kk + q < N ? kk + q : N - 1, N);
+#pragma unroll
+    for (int q = 0; q < 8; q++) a_pri = fmin(a_pri, v8[q]);
+  }
   double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -58,9 +64,11 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
     for (int i = 0; i < 2; i++) co += K.p.r_du[i] * (tu[i] - tv[i]) * (tu[i] - tv[i]);
     // sum of log t as the log of products of 8 slacks (same grouping in linearise_slot): 3 logarithms instead of 23
     double sl = 0.0, pr = 1.0;
+    double tt[BP::fixed ? MAX_NI : 1];  // compile-time bound pattern: the slacks of the candidate in one batch of loads
+    if (BP::fixed) for_each_bound<BP>(K.p, [&](int mm, int, int, double, double) { tt[mm] = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N); });
     const int m = for_each_bound<BP>(K.p, [&](int mm, int kind, int jj, double sg, double val) {
       const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
-      const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+      const double t = BP::fixed ? tt[mm] : PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
       th += fabs(sg * (xv - val) + t), pr *= t;
       if ((mm & 7) == 7) sl += log(pr), pr = 1.0;
     });
