@@ -562,9 +562,12 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   }
 #pragma unroll
   for (int a = 0; a < 8; a++) gphid += S.gcost[a] * dxp[a];
-  // (one flat visitor: an earlier version with a second, nested by-reference lambda produced run-to-run varying
-  //  values of gphid for the last interval on ROCm 7.2 / gfx950, a code-generation problem that instrumenting stores
-  //  made disappear; tests/test_gpu_parity.py::test_full_size_batch_properties guards against its return)
+  // (Code-generation hazard on ROCm 7.2 / gfx950, seen twice in this function: run-to-run varying values in the LAST
+  //  interval only (gphid; later dT / dNU of three Radau-point bounds), each time in a build of this kernel with
+  //  100 - 160 spilled SGPRs (v_writelane / v_readlane), gone after an unrelated change of the source.  The kernel
+  //  now reads K and W through pointers (under 30 spilled SGPRs); tests/test_gpu_parity.py guards against a return:
+  //  test_full_size_batch_properties (repeatability) and the bit-equality of the two instantiations in
+  //  test_compaction_and_serial_riccati_do_not_change_results.)
   // With a compile-time bound pattern the slacks and multipliers are fetched in one batch before the loop (on gfx9 a
   // load that follows a store waits for the store as well, vmcnt counts both in order: interleaved with the stores
   // of dT / dNU every bound cost a load AND a store round trip).  Run-time pattern: the index m is not a constant,
@@ -618,7 +621,9 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
 }
 
 template <class BP>
-__global__ void __launch_bounds__(64) k_expand(Consts K, Work W, Launch la) {
+__global__ void __launch_bounds__(64) k_expand(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;

@@ -65,6 +65,7 @@ struct ltompc_solver {
   Consts* d_K = nullptr;  // device copies of K and W for the solver kernels
   Work* d_W = nullptr;
   bool bounds_ref = false;  // the parameters have the reference's bound pattern: kernels instantiated for it (LTOMPC_BOUNDS=any: never)
+  bool ref_eval = false, ref_expand = false, ref_ls = false, ref_step1 = false;  // per kernel (LTOMPC_BOUNDS=eval,expand,...: those run generic)
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
@@ -236,6 +237,11 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
       const char* bp = getenv("LTOMPC_BOUNDS");  // any: the run-time pattern kernels (tests)
       h->bounds_ref = ulb == BoundsRef::ulb && uub == BoundsRef::uub && xlb == BoundsRef::xlb && xub == BoundsRef::xub &&
                       !(bp && std::string(bp) == "any");
+      const std::string sel = bp ? bp : "";
+      h->ref_eval = h->bounds_ref && sel.find("eval") == std::string::npos;
+      h->ref_expand = h->bounds_ref && sel.find("expand") == std::string::npos;
+      h->ref_ls = h->bounds_ref && sel.find("linesearch") == std::string::npos;
+      h->ref_step1 = h->bounds_ref && sel.find("step1") == std::string::npos;
     }
     const char* s1 = getenv("LTOMPC_STEP1");
     if (s1) h->step1_width = atoi(s1);
@@ -292,6 +298,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   using tp = gptr<const double>;
   T.s_kappa = (tp)h->d_tables, T.kappa = (tp)(h->d_tables + n_table), T.s_arc = (tp)(h->d_tables + 2 * (size_t)n_table);
   T.n_left = (tp)(h->d_tables + 3 * (size_t)n_table), T.n_right = (tp)(h->d_tables + 4 * (size_t)n_table), T.v_ref = (tp)(h->d_tables + 5 * (size_t)n_table);
+  T.g0_kappa = tables[0], T.inv_kappa = (double)(n_table - 1) / (tables[n_table - 1] - tables[0]);
+  T.g0_arc = tables[2 * (size_t)n_table], T.inv_arc = (double)(n_table - 1) / (tables[3 * (size_t)n_table - 1] - tables[2 * (size_t)n_table]);
   // K is complete now: the solver kernels read it from device memory
   if (h->dalloc(&h->d_K, 1) || h->dalloc(&h->d_W, 1) ||
       hipMemcpyAsync(h->d_K, &h->K, sizeof(Consts), hipMemcpyHostToDevice, h->stream) != hipSuccess ||
@@ -387,7 +395,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   int it = 0;
   for (;; it++) {
     const int np = la.n_pad;
-    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->bounds_ref ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->ref_eval ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
     } else {
@@ -400,17 +408,17 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, h->bounds_ref ? k_expand<BoundsRef> : k_expand<BoundsAny>, N * np, h->K, h->W, la)) return -1;
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, h->ref_expand ? k_expand<BoundsRef> : k_expand<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
     if (n_launch <= h->step1_width) {
       // one workgroup per instance does both line-search phases, the filter test and the update
       L.block_threads = 320;
-      if (L.run(7, h->bounds_ref ? k_step1<BoundsRef> : k_step1<BoundsAny>, n_launch * 320, h->d_K, h->d_W, la)) return -1;
+      if (L.run(7, h->ref_step1 ? k_step1<BoundsRef> : k_step1<BoundsAny>, n_launch * 320, h->d_K, h->d_W, la)) return -1;
     } else {
-      if (L.run(3, h->bounds_ref ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
+      if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
       if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
       if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
         const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
-        if (L.run(3, h->bounds_ref ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
+        if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
         if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 1)) return -1;
       }
       if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;

@@ -41,6 +41,7 @@ template <class T> using gptr = T*;
 struct Tables {
   int n;
   gptr<const double> s_kappa, kappa, s_arc, n_left, n_right, v_ref;
+  double g0_kappa, inv_kappa, g0_arc, inv_arc;  // first knot and (n - 1) / span of the two grids: interval estimate of lut_eval
 };
 
 struct Bounds {
@@ -55,23 +56,31 @@ struct Bounds {
 
 // ---------------------------------------------------------------------------------------------- tables
 // Interval i with grid[i] <= s < grid[i+1], clamped to [0, n-2]: linear extrapolation outside the grid.
-__device__ __forceinline__ int lut_interval(const double* __restrict__ grid, int n, double s) {
-  double g0 = grid[0];
-  double inv = (double)(n - 1) / (grid[n - 1] - g0);
-  double fi = (s - g0) * inv;
-  int i = fi <= 0.0 ? 0 : (fi >= (double)(n - 2) ? n - 2 : (int)fi);
-  while (i > 0 && s < grid[i]) --i;
-  while (i < n - 2 && s >= grid[i + 1]) ++i;
-  return i;
-}
-
+// g0 = grid[0] and inv = (n - 1) / (grid[n-1] - grid[0]) come with the tables (Tables::g0_*, inv_*).
+//
 // value / slope / second derivative of a table.  eps = 0: exact piece-wise linear.  eps > 0: each interior
 // knot's kink (J/2)|z| is replaced on |z| < W (W = half the shorter adjacent interval) by the C1 patch
 // (J/2)(sqrt(z^2+eps^2) + a z^2 + b) with k(W) = W, k'(W) = 1  (DESIGN.md "non-smoothness").
-__device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const double* __restrict__ y, int n,
-                                         double s, double eps, double& val, double& slope, double& curv) {
-  int i = lut_interval(grid, n, s);
-  double gi = grid[i], gi1 = grid[i + 1], yi = y[i], yi1 = y[i + 1];
+//
+// Memory: ONE round trip in the common case.  The interval is estimated from the (nearly) uniform spacing and the four
+// knots i-1 .. i+2 that the value and the rounding of either end can need are fetched together; only when the estimate
+// is off (the arc-length grid is not exactly uniform: 0.3 % of the lookups on the reference's tables) the interval is
+// searched and the knots are fetched again.  (Before: grid ends, search, values, neighbours, knot = 5 dependent loads,
+// 45 serialised round trips per slot in k_eval.)
+__device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const double* __restrict__ y, int n, double g0,
+                                         double inv, double s, double eps, double& val, double& slope, double& curv) {
+  const double fi = (s - g0) * inv;
+  int i = fi <= 0.0 ? 0 : (fi >= (double)(n - 2) ? n - 2 : (int)fi);
+  int im = i > 0 ? i - 1 : 0, ip = i + 2 < n ? i + 2 : n - 1;
+  double gm = grid[im], gi = grid[i], gi1 = grid[i + 1], gp = grid[ip];
+  double ym = y[im], yi = y[i], yi1 = y[i + 1], yp = y[ip];
+  if ((i > 0 && s < gi) || (i < n - 2 && s >= gi1)) {
+    while (i > 0 && s < grid[i]) --i;
+    while (i < n - 2 && s >= grid[i + 1]) ++i;
+    im = i > 0 ? i - 1 : 0, ip = i + 2 < n ? i + 2 : n - 1;
+    gm = grid[im], gi = grid[i], gi1 = grid[i + 1], gp = grid[ip];
+    ym = y[im], yi = y[i], yi1 = y[i + 1], yp = y[ip];
+  }
   double d = gi1 - gi;
   double sl = (yi1 - yi) / d;
   val = yi + sl * (s - gi);
@@ -81,16 +90,19 @@ __device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const 
     int kn = -1;
     double z = 0.0, W = 0.0, sg = 0.0;
     if (i > 0) {
-      double Wk = 0.5 * fmin(gi - grid[i - 1], d), zz = s - gi;
+      double Wk = 0.5 * fmin(gi - gm, d), zz = s - gi;
       if (zz >= 0.0 && zz < Wk) kn = i, z = zz, W = Wk, sg = 1.0;
     }
     if (kn < 0 && i + 1 < n - 1) {
-      double Wk = 0.5 * fmin(d, grid[i + 2] - gi1), zz = s - gi1;
+      double Wk = 0.5 * fmin(d, gp - gi1), zz = s - gi1;
       if (zz < 0.0 && -zz < Wk) kn = i + 1, z = zz, W = Wk, sg = -1.0;
     }
     if (kn > 0) {
-      double sa = (y[kn] - y[kn - 1]) / (grid[kn] - grid[kn - 1]);
-      double sb = (y[kn + 1] - y[kn]) / (grid[kn + 1] - grid[kn]);
+      const bool left = kn == i;  // knots kn-1, kn, kn+1
+      const double ga = left ? gm : gi, gb = left ? gi : gi1, gc = left ? gi1 : gp;
+      const double ya = left ? ym : yi, yb = left ? yi : yi1, yc = left ? yi1 : yp;
+      double sa = (yb - ya) / (gb - ga);
+      double sb = (yc - yb) / (gc - gb);
       double J = sb - sa, R = sqrt(z * z + eps * eps), RW = sqrt(W * W + eps * eps);
       double a = (1.0 - W / RW) / (2.0 * W), b = W - RW - a * W * W;
       val += 0.5 * J * (R + a * z * z + b - sg * z);
@@ -99,10 +111,10 @@ __device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const 
     }
   }
 }
-__device__ __forceinline__ double lut_val(const double* __restrict__ grid, const double* __restrict__ y, int n,
-                                          double s, double eps) {
+__device__ __forceinline__ double lut_val(const double* __restrict__ grid, const double* __restrict__ y, int n, double g0,
+                                          double inv, double s, double eps) {
   double v, sl, cv;
-  lut_eval(grid, y, n, s, eps, v, sl, cv);
+  lut_eval(grid, y, n, g0, inv, s, eps, v, sl, cv);
   return v;
 }
 
@@ -164,7 +176,7 @@ __device__ __forceinline__ void jet4_mul_delta(const Jet4& F, double s0, double 
 // Value-only right-hand side (plant, line search).  f[6], f[7] = u.
 __device__ __forceinline__ void rhs_val(const ltompc_params& p, const Tables& T, double eps, const double* x,
                                         const double* u, double* f) {
-  double kap = lut_val(T.s_kappa, T.kappa, T.n, x[0], eps);
+  double kap = lut_val(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, x[0], eps);
   double n = x[1], mu = x[2], vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
   double sm, cm, sd, cd;
   sincos(mu, &sm, &cm);
@@ -196,7 +208,7 @@ __device__ __forceinline__ void rhs_derivs(const ltompc_params& p, const Tables&
   for (int i = 0; i < 48; i++) J[i] = 0.0;
   // ---- kinematic rows (s, n, mu) over (s, n, mu, vx, vy)
   double kap, kp, kpp;
-  lut_eval(T.s_kappa, T.kappa, T.n, s, eps, kap, kp, kpp);
+  lut_eval(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, s, eps, kap, kp, kpp);
   double sm, cm;
   sincos(mu, &sm, &cm);
   double w = vx * cm - vy * sm, nd = vx * sm + vy * cm;
@@ -304,7 +316,7 @@ __device__ __forceinline__ double cost_eval(const ltompc_params& p, const Tables
   }
   if (terminal) return val;
   double vr, vr1, vr2;
-  lut_eval(T.s_arc, T.v_ref, T.n, x[0], eps, vr, vr1, vr2);
+  lut_eval(T.s_arc, T.v_ref, T.n, T.g0_arc, T.inv_arc, x[0], eps, vr, vr1, vr2);
   double cv = p.vref_scale;
   double e = vx - cv * vr;
   double rho = p.length_r / (p.length_f + p.length_r);
@@ -343,8 +355,8 @@ __device__ __forceinline__ double cost_eval(const ltompc_params& p, const Tables
 __device__ __forceinline__ void cons_eval(const ltompc_params& p, const Tables& T, double eps, const double* x,
                                           double* val, double* gs, double* gn, double* gm, double* hss, double* hmm) {
   double NL, NL1, NL2, NR, NR1, NR2;
-  lut_eval(T.s_arc, T.n_left, T.n, x[0], eps, NL, NL1, NL2);
-  lut_eval(T.s_arc, T.n_right, T.n, x[0], eps, NR, NR1, NR2);
+  lut_eval(T.s_arc, T.n_left, T.n, T.g0_arc, T.inv_arc, x[0], eps, NL, NL1, NL2);
+  lut_eval(T.s_arc, T.n_right, T.n, T.g0_arc, T.inv_arc, x[0], eps, NR, NR1, NR2);
   double hl = 0.5 * (p.length_f + p.length_r), hw = 0.5 * p.width;
   double mu = x[2], sm, cm;
   sincos(mu, &sm, &cm);
