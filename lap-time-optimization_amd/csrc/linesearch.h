@@ -123,16 +123,34 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   const ltompc_options& o = K.o;
   const double mu = STD(ST_MU);
   double a_pri = 1.0, a_dua = 1.0, gphid = 0.0;
-  for (int k = i; k < N; k += 8) {
-    a_pri = fmin(a_pri, PL(W.SP, SP_apri, k, N)), a_dua = fmin(a_dua, PL(W.SP, SP_adua, k, N));
-    gphid += PL(W.SP, SP_gphid, k, N);
+  // (loads of four stages in flight per round trip; the additions keep the order k = i, i + 8, ...)
+  for (int k0 = i; k0 < N; k0 += 32) {
+    double v[3][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + 8 * q < N ? k0 + 8 * q : k0;
+      v[0][q] = PL(W.SP, SP_apri, k, N), v[1][q] = PL(W.SP, SP_adua, k, N), v[2][q] = PL(W.SP, SP_gphid, k, N);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k0 + 8 * q < N) a_pri = fmin(a_pri, v[0][q]), a_dua = fmin(a_dua, v[1][q]), gphid += v[2][q];
   }
   a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
   // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
   const double c00 = STD(ST_C00);
   auto measures = [&](int l, double& th, double& ph) {
     double t = 0.0, c = 0.0, s = 0.0;
-    for (int k = i; k < N; k += 8) t += PL(W.LS, 3 * l + 0, k, N), c += PL(W.LS, 3 * l + 1, k, N), s += PL(W.LS, 3 * l + 2, k, N);
+    for (int k0 = i; k0 < N; k0 += 32) {
+      double v[3][4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int k = k0 + 8 * q < N ? k0 + 8 * q : k0;
+        v[0][q] = PL(W.LS, 3 * l + 0, k, N), v[1][q] = PL(W.LS, 3 * l + 1, k, N), v[2][q] = PL(W.LS, 3 * l + 2, k, N);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (k0 + 8 * q < N) t += v[0][q], c += v[1][q], s += v[2][q];
+    }
     t = grp_sum(t), c = grp_sum(c), s = grp_sum(s);
     th = t, ph = (c00 + c) - mu * s;
   };

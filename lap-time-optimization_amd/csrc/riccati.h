@@ -311,7 +311,17 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
   double smult = 0.0, obj;
   obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
-  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  for (int k0 = 0; k0 < N; k0 += 8) {  // same order of additions as the serial kernel, eight loads in flight per round trip
+    double sm8[8], co8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int k = k0 + q < N ? k0 + q : N - 1;
+      sm8[q] = PL(W.RS, RS_smult, k, N), co8[q] = PL(W.RS, RS_cost, k, N);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (k0 + q < N) smult += sm8[q], obj += co8[q];
+  }
   const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
@@ -685,7 +695,17 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
   double smult = 0.0, obj;
   obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
-  for (int k = 0; k < N; k++) smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+  for (int k0 = 0; k0 < N; k0 += 8) {  // same order of additions as the serial kernel, eight loads in flight per round trip
+    double sm8[8], co8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int k = k0 + q < N ? k0 + q : N - 1;
+      sm8[q] = PL(W.RS, RS_smult, k, N), co8[q] = PL(W.RS, RS_cost, k, N);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (k0 + q < N) smult += sm8[q], obj += co8[q];
+  }
   const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
