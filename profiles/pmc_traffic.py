@@ -16,12 +16,18 @@ B, N = 8192, 40
 UPDATE_READ, UPDATE_WRITE = 160 * 8, 80 * 8  # bytes per (instance, interval)
 
 
+def kname(n):
+    """ltompc::k_eval<...>(args) / void ltompc::k_eval<ltompc::BoundsFixed<...> >(args) -> k_eval"""
+    import re
+    return re.sub(r"[<(].*", "", n.replace("void ", "").replace("ltompc::", "")).strip()
+
+
 def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
-            out[r["Kernel_Name"].split("(")[0].replace("ltompc::", "")].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+            out[kname(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     return out
 
 

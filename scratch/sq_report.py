@@ -4,7 +4,8 @@ root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/sq"
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("ltompc::", "")
+        import re
+        k = re.sub(r"[<(].*", "", r["Kernel_Name"].replace("void ", "").replace("ltompc::", "")).strip()
         vals[k][r["Counter_Name"]].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
 kern = ["k_eval", "k_expand", "k_riccati8", "k_linesearch", "k_update"]
 names = sorted({c for k in kern for c in vals[k]})
@@ -23,6 +24,8 @@ for c in names:
     print(f"{c:28s}" + "".join(f"{x:16.4g}" for x in row))
 print()
 def ratio(a, b, label):
+    if a not in tab or b not in tab:
+        return
     print(f"{label:28s}" + "".join(f"{(x / y if y else float('nan')):16.3f}" for x, y in zip(tab[a], tab[b])))
 ratio("SQ_WAVE_CYCLES", "SQ_INSTS_VALU", "wave cycles / VALU inst")
 ratio("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "VALU active / wave cycles")
