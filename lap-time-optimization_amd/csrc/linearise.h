@@ -498,6 +498,9 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
       pi[i] = s;
     }
   }
+  // (nothing may be scheduled across this point: without it the compiler hoists the ~100 loads of the linearisation
+  //  above the costate, runs out of registers and spills the Riccati words one by one, each spill waiting for its load)
+  __builtin_amdgcn_sched_barrier(0);
   Slot S;
   linearise_slot<false, BP>(K, W, k, b, eps, S);
   M8Blocks M8;

@@ -21,6 +21,17 @@ def test_model_derivatives_match_oracle_ad(pkg, tables, oracle, gpu_lib, eps):
     """Hand-derived analytic derivatives in the kernels == forward-mode AD in the oracle (rel 1e-11)."""
     n = 200
     x, lam = _points(pkg, tables, n)
+    # table look-ups whose interval estimate (uniform spacing) is off by one: the arc-length grid is not exactly
+    # uniform; also exact knots, the first / last interval and points outside the grid (linear extrapolation)
+    g = tables.s_arc
+    inv = (len(g) - 1) / (g[-1] - g[0])
+    s_try = np.concatenate([g[1:-1] - 1e-9, g[1:-1] + 1e-9, g[1:-1]])
+    est = np.clip(((s_try - g[0]) * inv).astype(int), 0, len(g) - 2)
+    true = np.clip(np.searchsorted(g, s_try, side="right") - 1, 0, len(g) - 2)
+    off = s_try[est != true]
+    assert len(off) >= 8
+    special = np.concatenate([off[:: max(1, len(off) // 24)][:24], g[[1, 2, 400, len(g) - 2]], [g[0] + 0.3, g[-1] - 0.3, g[0] - 2.0, g[-1] + 2.0]])
+    x[: len(special), 0] = special
     mpc = pkg.BatchedMPC(tables, 10, 1)
     out = mpc.test_model(x, lam, eps)
     for i in range(n):
