@@ -200,7 +200,10 @@ int ltompc_get_history(ltompc_handle h, int* triples, int capacity);
 /* make_step polls the device's count of unfinished instances every n interior-point iterations (default 4). */
 int ltompc_set_poll_every(ltompc_handle h, int n);
 
-/* Debug hook: raw copy of a device work array in its device layout (see csrc/kernels.h); returns its size in bytes. */
+/* Debug hook: raw copy of a device work array in its device layout (see csrc/kernels.h); returns its size in bytes.
+ * Work arrays are indexed by the physical slot of an instance; a solve that re-packed its unfinished instances
+ * (more than 4 iterations) uses the step buffers as temporaries when it restores the caller's order,
+ * so their content is meaningful after solves capped at a few iterations only (which is what the tests do). */
 long long ltompc_debug_fetch(ltompc_handle h, int which, void* out, long long nbytes);
 
 /* Test hook (not part of the reference surface): model derivatives at n points, computed by the same device

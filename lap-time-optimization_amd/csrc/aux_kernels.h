@@ -144,6 +144,76 @@ __global__ void __launch_bounds__(1024) k_compact(const int* __restrict__ src, c
   if (t == 1023) ndst[0] = cnt[1023];
 }
 
+// ------------------------------------------------------------------------------------------ packing
+// Index compaction alone leaves the unfinished instances where they are: at 55 % density a wavefront's 64 lanes span
+// ~116 instances and every load moves twice the sectors it uses (measured: launches of 4500 instances as slow as
+// launches of 8192).  Packing moves the instances themselves: the first `nslots` physical slots are permuted so that
+// the unfinished ones come first (stable), the list becomes the identity, `orig` remembers where every slot came from.
+// The step buffers (free between two iterations) and the Riccati buffer are the temporaries.
+__global__ void __launch_bounds__(1024) k_pack_perm(const int* __restrict__ nslots_p, const int* __restrict__ done, int* __restrict__ perm,
+                                                     int* __restrict__ act, int* __restrict__ nact) {
+  __shared__ int cnt[1024];
+  const int t = threadIdx.x, n = nslots_p[0];
+  const int chunk = (n + 1023) / 1024, lo = min(n, t * chunk), hi = min(n, lo + chunk);
+  int c = 0;
+  for (int j = lo; j < hi; j++) c += done[j] ? 0 : 1;
+  cnt[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
+    int v = t >= off ? cnt[t - off] : 0;
+    __syncthreads();
+    cnt[t] += v;
+    __syncthreads();
+  }
+  const int n_act = cnt[1023];
+  int pa = cnt[t] - c, pd = n_act + lo - pa;  // unfinished before this chunk; finished before it = lo - pa
+  for (int j = lo; j < hi; j++) {
+    if (!done[j]) act[pa] = pa, perm[pa++] = j;
+    else perm[pd++] = j;
+  }
+  if (t == 0) nact[0] = n_act;
+}
+// inverse of `orig` (for the final un-packing: slot j goes back to orig[j])
+__global__ void k_pack_inverse(const int* __restrict__ orig, int* __restrict__ inv, int B) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < B) inv[orig[j]] = j;
+}
+// pass 0: temporaries[j] = state[perm[j]], pass 1: state[j] = temporaries[j], for the slots j < nslots
+__global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restrict__ nslots_p, int nslots_max, int* __restrict__ orig,
+                       int ni, int pass) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = tid % nslots_max, k = tid / nslots_max, N = W.N;
+  const int nslots = nslots_p ? nslots_p[0] : nslots_max;
+  if (k > N || j >= nslots) return;
+  const size_t Bp = W.Bp;
+  const size_t s = pass == 0 ? perm[j] : j;  // source slot
+  auto mv = [&](gptr<double> dst, gptr<double> src, int nf, int NK) {
+    for (int f = 0; f < nf; f++) dst[((size_t)f * NK + k) * Bp + j] = src[((size_t)f * NK + k) * Bp + s];
+  };
+  if (pass == 0) {
+    mv(W.dX, W.X, 8, N + 1);
+    if (k < N) mv(W.dC, W.C, 8, N), mv(W.dU, W.U, 2, N), mv(W.nL1, W.L1, 8, N), mv(W.nL2, W.L2, 8, N), mv(W.dT, W.T, ni + 3, N), mv(W.dNU, W.NU, ni, N);
+  } else {
+    mv(W.X, W.dX, 8, N + 1);
+    if (k < N) mv(W.C, W.dC, 8, N), mv(W.U, W.dU, 2, N), mv(W.L1, W.nL1, 8, N), mv(W.L2, W.nL2, 8, N), mv(W.T, W.dT, ni + 3, N), mv(W.NU, W.dNU, ni, N);
+  }
+  if (k == 0) {  // per-instance arrays through the Riccati buffer: x0 (8), uprev (2), st, filt | si, orig (ints)
+    gptr<double> tmp = W.RC;
+    gptr<int> itmp = (gptr<int>)(W.RC + (size_t)(10 + ST_NF + 2 * FILTER_MAX) * Bp);
+    for (int f = 0; f < 10 + ST_NF + 2 * FILTER_MAX; f++) {
+      gptr<double> a = f < 8 ? W.x0 + (size_t)f * Bp : f < 10 ? W.uprev + (size_t)(f - 8) * Bp
+                       : f < 10 + ST_NF ? W.st + (size_t)(f - 10) * Bp : W.filt + (size_t)(f - 10 - ST_NF) * Bp;
+      if (pass == 0) tmp[(size_t)f * Bp + j] = a[s];
+      else a[j] = tmp[(size_t)f * Bp + j];
+    }
+    for (int f = 0; f <= SI_NF; f++) {
+      gptr<int> a = f < SI_NF ? W.si + (size_t)f * Bp : (gptr<int>)orig;
+      if (pass == 0) itmp[(size_t)f * Bp + j] = a[s];
+      else a[j] = itmp[(size_t)f * Bp + j];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ I/O helpers
 // row-major (B x 8) user buffer -> [8][Bp] planes
 __global__ void k_load_x0(Work W, const double* __restrict__ x0_rm) {

@@ -357,8 +357,8 @@ __global__ void __launch_bounds__(64) k_eval8(const Consts* __restrict__ Kp, con
   const bool valid = j < la.nact[0];
   const int b = la.act[valid ? j : 0];
   const int* si = W.si;
-  const bool live = valid && !si[(size_t)SI_DONE * W.Bp + b] && !si[(size_t)SI_RETRY * W.Bp + b] &&
-                    !si[(size_t)SI_SKIP_EVAL * W.Bp + b];  // else: the blocks of the last launch are still valid
+  const bool live = valid && !si[(size_t)SI_DONE * W.Bp + b] &&
+                    (la.force_eval || (!si[(size_t)SI_RETRY * W.Bp + b] && !si[(size_t)SI_SKIP_EVAL * W.Bp + b]));  // else: the blocks of the last launch are still valid
   if (!__any(live)) return;
   d_eval8(K, W, lds[g], i, k, b, live);
 }

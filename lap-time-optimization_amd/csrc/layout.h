@@ -76,6 +76,7 @@ struct Launch {
   gptr<const int> act;
   gptr<const int> nact;
   int n_pad;  // launch width rounded up to a multiple of 64
+  int force_eval;  // the instances have just been moved (k_pack): the stage blocks of the last launch are not where they were
 };
 
 struct Consts {

@@ -366,10 +366,10 @@ __device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8
 
 // ------------------------------------------------------------------------------------------ k_eval
 template <class BP>
-__device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b) {
+__device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b, const bool force) {
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
-  if (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b]) return;  // blocks of the last launch are still valid
+  if (!force && (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b])) return;  // blocks of the last launch are still valid
   const double hdt = K.o.t_step;
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
   Slot S;
@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(64) k_eval(const Consts* __restrict__ Kp, cons
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
-  d_eval<BP>(K, W, k, la.act[j]);
+  d_eval<BP>(K, W, k, la.act[j], la.force_eval != 0);
 }
 
 

@@ -46,6 +46,8 @@ struct ltompc_solver {
   int* h_active = nullptr;     // pinned
   int *d_act[2] = {nullptr, nullptr}, *d_nact[2] = {nullptr, nullptr};  // ping-pong lists of unfinished instances
   int last_compactions = 0;
+  int *d_perm = nullptr, *d_orig = nullptr;  // packing: permutation of the current re-packing, original index of every physical slot
+  bool packing = true;  // LTOMPC_PACK=0: re-pack the list of unfinished instances only, leave their data where it is
   std::vector<int> history;  // (iteration, n_active, n_launch) triples of the last make_step's polls
   bool cold_next = true;
   int poll_every = 4;
@@ -227,6 +229,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->serial_riccati = e && std::string(e) == "serial";
     const char* c = getenv("LTOMPC_COMPACT");
     h->compaction = !(c && std::string(c) == "0");
+    const char* pk = getenv("LTOMPC_PACK");
+    h->packing = !(pk && std::string(pk) == "0");
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
     h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
     if (ev) h->eval8 = std::string(ev) == "wave";
@@ -278,6 +282,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
+  rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
@@ -393,8 +398,11 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   h->last_compactions = 0;
   h->history.clear();
   int it = 0;
+  bool packed_any = false, force_eval_next = false;
   for (;; it++) {
     const int np = la.n_pad;
+    la.force_eval = force_eval_next ? 1 : 0;
+    force_eval_next = false;
     if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->ref_eval ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
@@ -431,9 +439,23 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
       if (h->compaction && n_active <= (3 * n_launch) / 4) {
-        // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack the list
-        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
-                           h->W.si + (size_t)SI_DONE * Bp, h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+        // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack
+        if (h->packing) {
+          // ... the instances themselves (the first nact slots are permuted, unfinished ones first; k_pack in
+          // aux_kernels.h), so that the lanes of a wavefront keep touching neighbouring addresses
+          if (!packed_any) hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
+          packed_any = true;
+          hipLaunchKernelGGL(k_pack_perm, dim3(1), dim3(1024), 0, h->stream, h->d_nact[cur], h->W.si + (size_t)SI_DONE * Bp, h->d_perm,
+                             h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+          const int nthreads = (N + 1) * n_launch;
+          for (int pass = 0; pass < 2; pass++)
+            hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, h->d_nact[cur], n_launch,
+                               h->d_orig, h->K.bd.ni, pass);
+          force_eval_next = true;  // the stage blocks of instances that would skip the evaluation stayed behind
+        } else {
+          hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
+                             h->W.si + (size_t)SI_DONE * Bp, h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+        }
         cur ^= 1;
         set_launch(n_active);  // upper bound of the compacted count; kernels test against the device-side count
         h->last_compactions++;
@@ -441,6 +463,13 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     }
   }
   if (L.close()) return -1;
+  if (packed_any) {  // back to the caller's order: slot j returns to orig[j]
+    hipLaunchKernelGGL(k_pack_inverse, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
+    const int nthreads = (N + 1) * B;
+    for (int pass = 0; pass < 2; pass++)
+      hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, (const int*)nullptr, B, h->d_orig,
+                         h->K.bd.ni, pass);
+  }
   hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev);
   HIPCHECK(hipGetLastError());
   h->last_launches = L.launches + 3;

@@ -224,8 +224,10 @@ def test_warm_start_options_match_oracle(pkg, tables, orc, gpu_lib):
 
 
 def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_lib, monkeypatch):
-    """Packing of unfinished instances and the wave-cooperative Riccati kernel are pure scheduling: results are
-    bit-identical with compaction switched off, and equal to 1e-9 with the one-thread-per-instance Riccati kernel."""
+    """Packing of unfinished instances (their data is moved to the front of the batch and back at the end of the
+    solve) and the choice of kernels are pure scheduling: results are bit-identical with packing switched off, with
+    index-only re-packing, with the narrow-launch kernels switched off and with the run-time bound-pattern kernels, and
+    equal to 1e-6 with the one-thread-per-instance Riccati kernel."""
     B, N = 300, 20
     x0 = pkg.sample_x0(tables, B, seed=9)
     def run():
@@ -240,6 +242,11 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     solved = s_ref["status"] == 0   # (iteration counts of unsolved instances depend on how many launches they were given)
     assert np.array_equal(s_nc["iters"][solved], s_ref["iters"][solved])
     monkeypatch.setenv("LTOMPC_COMPACT", "1")
+    monkeypatch.setenv("LTOMPC_PACK", "0")   # re-packing of the index list only vs moving the instances' data: same bits
+    u_np, s_np = run()
+    assert np.array_equal(u_np, u_ref) and np.array_equal(s_np["status"], s_ref["status"])
+    assert np.array_equal(s_np["iters"][solved], s_ref["iters"][solved]) and np.array_equal(s_np["kkt"][solved], s_ref["kkt"][solved])
+    monkeypatch.delenv("LTOMPC_PACK")
     monkeypatch.setenv("LTOMPC_RIC1", "0")   # 8-instances-per-wavefront sweep only vs one wavefront per instance in narrow launches: same bits
     monkeypatch.setenv("LTOMPC_STEP1", "0")  # separate line-search / pick / update launches vs the fused step-selection kernel: same bits
     u_nt, s_nt = run()
