@@ -47,11 +47,12 @@ struct ltompc_solver {
   int *d_act[2] = {nullptr, nullptr}, *d_nact[2] = {nullptr, nullptr};  // ping-pong lists of unfinished instances
   int last_compactions = 0;
   int *d_perm = nullptr, *d_orig = nullptr;  // packing: permutation of the current re-packing, original index of every physical slot
+  int pack_num = 6;  // re-pack when at most pack_num / 8 of the launch width is still unfinished (LTOMPC_PACK_NUM)
   bool packing = true;  // LTOMPC_PACK=0: re-pack the list of unfinished instances only, leave their data where it is
   std::vector<int> history;  // (iteration, n_active, n_launch) triples of the last make_step's polls
   bool cold_next = true;
   int poll_every = 4;
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every launch bracketed, 2 + c: launches of kernel class c only
   bool compaction = true;       // LTOMPC_COMPACT=0 switches the re-packing of unfinished instances off
   bool serial_riccati = false;  // LTOMPC_RICCATI=serial selects the one-thread-per-instance kernel (A/B checks)
   // profiling: ONE event before every launch (and one closing a run of launches before the host waits); a launch's
@@ -125,7 +126,13 @@ struct Launcher {
     dim3 block(block_threads), grid((threads_total + block_threads - 1) / block_threads);
     const size_t lds_bytes = lds;
     lds = 0, block_threads = 64;
-    if (h->profiling && stamp(kind)) return -1;
+    if (h->profiling == 1) {
+      if (stamp(kind)) return -1;
+    } else if (h->profiling >= 2) {  // one class only: open before its launches, close before the next launch of another class
+      if (kind == h->profiling - 2) {
+        if (stamp(kind)) return -1;
+      } else if (!h->ev_kind.empty() && h->ev_kind.back() >= 0 && stamp(-1)) return -1;
+    }
     hipLaunchKernelGGL(kern, grid, block, lds_bytes, h->stream, args...);
     launches++;
     return 0;
@@ -231,6 +238,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->compaction = !(c && std::string(c) == "0");
     const char* pk = getenv("LTOMPC_PACK");
     h->packing = !(pk && std::string(pk) == "0");
+    const char* pn = getenv("LTOMPC_PACK_NUM");
+    if (pn && atoi(pn) >= 1 && atoi(pn) <= 7) h->pack_num = atoi(pn);
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
     h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
     if (ev) h->eval8 = std::string(ev) == "wave";
@@ -337,7 +346,8 @@ int ltompc_set_stream(ltompc_handle h, void* hip_stream) {
 
 int ltompc_set_profiling(ltompc_handle h, int on) {
   if (!h) return fail("null handle");
-  h->profiling = on != 0;
+  if (on < 0 || on >= 2 + NKERN) return fail("ltompc_set_profiling: mode out of range");
+  h->profiling = on;
   for (int i = 0; i < NKERN; i++) h->ms_by_kernel[i] = 0, h->launches_by_kernel[i] = 0;
   h->log_kind.clear(), h->log_width.clear(), h->log_ms.clear();
   return 0;
@@ -438,7 +448,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
       h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
-      if (h->compaction && n_active <= (3 * n_launch) / 4) {
+      if (h->compaction && n_active <= (h->pack_num * n_launch) / 8) {
         // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack
         if (h->packing) {
           // ... the instances themselves (the first nact slots are permuted, unfinished ones first; k_pack in

@@ -9,6 +9,8 @@ from . import _lib
 from ._lib import NX, NU, Options, Params, check, dptr, iptr, lib
 from .tables import TrackTables
 
+KERNEL_CLASSES = ("eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1")  # include/ltompc.h
+
 
 class BatchedMPC:
     """B receding-horizon NLPs of the reference's controller (src/mpc/controller.py:9-103), solved on the GPU.
@@ -100,8 +102,12 @@ class BatchedMPC:
         check(lib().ltompc_slip_forces(self._h, dptr(x), x.shape[0], dptr(a), dptr(F)))
         return a, F
 
-    def set_profiling(self, on: bool):
-        check(lib().ltompc_set_profiling(self._h, int(on)))
+    def set_profiling(self, on, only: str | None = None):
+        """on: False / True (every launch).  only='eval' | 'riccati' | ...: bracket the launches of that kernel class only."""
+        mode = int(bool(on))
+        if on and only is not None:
+            mode = 2 + KERNEL_CLASSES.index(only)
+        check(lib().ltompc_set_profiling(self._h, mode))
 
     def set_poll_every(self, n: int):
         check(lib().ltompc_set_poll_every(self._h, int(n)))
@@ -110,7 +116,7 @@ class BatchedMPC:
         ms, ln = np.zeros(8), np.zeros(8, dtype=np.int32)
         launches, its = C.c_int(), C.c_int()
         check(lib().ltompc_get_timing(self._h, dptr(ms), iptr(ln), C.byref(launches), C.byref(its)))
-        names = ("eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1")
+        names = KERNEL_CLASSES
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
 
