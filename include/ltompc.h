@@ -102,6 +102,10 @@ typedef struct ltompc_options {
                              restarts the equality multipliers at 0 and the barrier at mu_init (IPOPT's default
                              warm_start_init_point=no never re-uses multipliers; ours are re-used after a converged
                              solve only, the ones of a failed solve are what diverged) | 0: always re-use       (1) */
+  int periodic_tables;    /* 0: tables extrapolate linearly beyond their ends (CasADi's interpolant, the reference) | 1: the track is a
+                             closed loop, tables are evaluated at s modulo their span (buckmore: kappa, n_left, n_right
+                             agree at both ends, v_ref to 0.2 %), so that the closed loop can run lap after lap; the kink
+                             at the seam is not rounded                                      (0) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),

@@ -313,6 +313,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   T.s_kappa = (tp)h->d_tables, T.kappa = (tp)(h->d_tables + n_table), T.s_arc = (tp)(h->d_tables + 2 * (size_t)n_table);
   T.n_left = (tp)(h->d_tables + 3 * (size_t)n_table), T.n_right = (tp)(h->d_tables + 4 * (size_t)n_table), T.v_ref = (tp)(h->d_tables + 5 * (size_t)n_table);
   T.g0_kappa = tables[0], T.inv_kappa = (double)(n_table - 1) / (tables[n_table - 1] - tables[0]);
+  T.period = options->periodic_tables ? tables[n_table - 1] - tables[0] : 0.0;
   T.g0_arc = tables[2 * (size_t)n_table], T.inv_arc = (double)(n_table - 1) / (tables[3 * (size_t)n_table - 1] - tables[2 * (size_t)n_table]);
   // K is complete now: the solver kernels read it from device memory
   if (h->dalloc(&h->d_K, 1) || h->dalloc(&h->d_W, 1) ||

@@ -42,6 +42,7 @@ struct Tables {
   int n;
   gptr<const double> s_kappa, kappa, s_arc, n_left, n_right, v_ref;
   double g0_kappa, inv_kappa, g0_arc, inv_arc;  // first knot and (n - 1) / span of the two grids: interval estimate of lut_eval
+  double period;  // options.periodic_tables: span of the grids (tables evaluated at s modulo the span), else 0
 };
 
 struct Bounds {
@@ -68,7 +69,8 @@ struct Bounds {
 // searched and the knots are fetched again.  (Before: grid ends, search, values, neighbours, knot = 5 dependent loads,
 // 45 serialised round trips per slot in k_eval.)
 __device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const double* __restrict__ y, int n, double g0,
-                                         double inv, double s, double eps, double& val, double& slope, double& curv) {
+                                         double inv, double period, double s, double eps, double& val, double& slope, double& curv) {
+  if (period > 0.0) s -= period * floor((s - g0) / period);  // closed track: same table lap after lap (exact no-op on the first)
   const double fi = (s - g0) * inv;
   int i = fi <= 0.0 ? 0 : (fi >= (double)(n - 2) ? n - 2 : (int)fi);
   int im = i > 0 ? i - 1 : 0, ip = i + 2 < n ? i + 2 : n - 1;
@@ -112,9 +114,9 @@ __device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const 
   }
 }
 __device__ __forceinline__ double lut_val(const double* __restrict__ grid, const double* __restrict__ y, int n, double g0,
-                                          double inv, double s, double eps) {
+                                          double inv, double period, double s, double eps) {
   double v, sl, cv;
-  lut_eval(grid, y, n, g0, inv, s, eps, v, sl, cv);
+  lut_eval(grid, y, n, g0, inv, period, s, eps, v, sl, cv);
   return v;
 }
 
@@ -176,7 +178,7 @@ __device__ __forceinline__ void jet4_mul_delta(const Jet4& F, double s0, double 
 // Value-only right-hand side (plant, line search).  f[6], f[7] = u.
 __device__ __forceinline__ void rhs_val(const ltompc_params& p, const Tables& T, double eps, const double* x,
                                         const double* u, double* f) {
-  double kap = lut_val(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, x[0], eps);
+  double kap = lut_val(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, T.period, x[0], eps);
   double n = x[1], mu = x[2], vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
   double sm, cm, sd, cd;
   sincos(mu, &sm, &cm);
@@ -208,7 +210,7 @@ __device__ __forceinline__ void rhs_derivs(const ltompc_params& p, const Tables&
   for (int i = 0; i < 48; i++) J[i] = 0.0;
   // ---- kinematic rows (s, n, mu) over (s, n, mu, vx, vy)
   double kap, kp, kpp;
-  lut_eval(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, s, eps, kap, kp, kpp);
+  lut_eval(T.s_kappa, T.kappa, T.n, T.g0_kappa, T.inv_kappa, T.period, s, eps, kap, kp, kpp);
   double sm, cm;
   sincos(mu, &sm, &cm);
   double w = vx * cm - vy * sm, nd = vx * sm + vy * cm;
@@ -316,7 +318,7 @@ __device__ __forceinline__ double cost_eval(const ltompc_params& p, const Tables
   }
   if (terminal) return val;
   double vr, vr1, vr2;
-  lut_eval(T.s_arc, T.v_ref, T.n, T.g0_arc, T.inv_arc, x[0], eps, vr, vr1, vr2);
+  lut_eval(T.s_arc, T.v_ref, T.n, T.g0_arc, T.inv_arc, T.period, x[0], eps, vr, vr1, vr2);
   double cv = p.vref_scale;
   double e = vx - cv * vr;
   double rho = p.length_r / (p.length_f + p.length_r);
@@ -355,8 +357,8 @@ __device__ __forceinline__ double cost_eval(const ltompc_params& p, const Tables
 __device__ __forceinline__ void cons_eval(const ltompc_params& p, const Tables& T, double eps, const double* x,
                                           double* val, double* gs, double* gn, double* gm, double* hss, double* hmm) {
   double NL, NL1, NL2, NR, NR1, NR2;
-  lut_eval(T.s_arc, T.n_left, T.n, T.g0_arc, T.inv_arc, x[0], eps, NL, NL1, NL2);
-  lut_eval(T.s_arc, T.n_right, T.n, T.g0_arc, T.inv_arc, x[0], eps, NR, NR1, NR2);
+  lut_eval(T.s_arc, T.n_left, T.n, T.g0_arc, T.inv_arc, T.period, x[0], eps, NL, NL1, NL2);
+  lut_eval(T.s_arc, T.n_right, T.n, T.g0_arc, T.inv_arc, T.period, x[0], eps, NR, NR1, NR2);
   double hl = 0.5 * (p.length_f + p.length_r), hw = 0.5 * p.width;
   double mu = x[2], sm, cm;
   sincos(mu, &sm, &cm);

@@ -137,6 +137,7 @@ typedef struct {
   const double *s_kappa, *kappa, *s_arc, *n_left, *n_right, *v_ref;
   double eps_s;  /* table-kink smoothing length [m]  (0 = exact PWL)        */
   double eps_mu; /* |mu| smoothing [rad]             (0 = exact sin|mu|)    */
+  double period; /* options.periodic_tables: span of the grids, tables evaluated at s modulo it; else 0 */
 } tables_t;
 
 static tables_t tables_view(const double* packed, int n) {
@@ -148,7 +149,7 @@ static tables_t tables_view(const double* packed, int n) {
   t.n_left = packed + 3 * n;
   t.n_right = packed + 4 * n;
   t.v_ref = packed + 5 * n;
-  t.eps_s = 0.0, t.eps_mu = 0.0;
+  t.eps_s = 0.0, t.eps_mu = 0.0, t.period = 0.0;
   return t;
 }
 /* CasADi linear interpolant: interval i with grid[i] <= s < grid[i+1], clamped to [0, n-2] => linear
@@ -168,8 +169,9 @@ static int lut_interval(const double* grid, int n, double s) {
  *   k(z) = sqrt(z^2 + eps^2) + a z^2 + b,   a, b such that k(W) = W, k'(W) = 1,
  * i.e. a compact-support pseudo-Huber patch: C1 everywhere, identical to the PWL table outside the windows,
  * -> |z| as eps -> 0 (max deviation (J/2) eps at the knot).  See DESIGN.md "non-smoothness". */
-static void lut_eval2(const double* grid, const double* y, int n, double s, double eps, double* val, double* slope,
-                      double* curv) {
+static void lut_eval2(const double* grid, const double* y, int n, double s, double eps, double period, double* val,
+                      double* slope, double* curv) {
+  if (period > 0.0) s -= period * floor((s - grid[0]) / period); /* closed track (options.periodic_tables) */
   int i = lut_interval(grid, n, s);
   double d = grid[i + 1] - grid[i];
   double sl = (y[i + 1] - y[i]) / d;
@@ -198,14 +200,14 @@ static void lut_eval2(const double* grid, const double* y, int n, double s, doub
     }
   }
 }
-static jet jlut(const double* grid, const double* y, int n, jet s, double eps) {
+static jet jlut(const double* grid, const double* y, int n, jet s, double eps, double period) {
   double v, sl, cv;
-  lut_eval2(grid, y, n, s.v, eps, &v, &sl, &cv);
+  lut_eval2(grid, y, n, s.v, eps, period, &v, &sl, &cv);
   return junary(s, v, sl, cv);
 }
-static double lut_val(const double* grid, const double* y, int n, double s, double eps) {
+static double lut_val(const double* grid, const double* y, int n, double s, double eps, double period) {
   double v, sl, cv;
-  lut_eval2(grid, y, n, s, eps, &v, &sl, &cv);
+  lut_eval2(grid, y, n, s, eps, period, &v, &sl, &cv);
   return v;
 }
 
@@ -232,7 +234,7 @@ static void slip_forces_jet(const ltompc_params* p, jet vx, jet vy, jet r, jet d
 static void rhs_jet(const ltompc_params* p, const tables_t* T, const double* x, rhs_jets* out) {
   jet s = jvar(x[0], 0), n = jvar(x[1], 1), mu = jvar(x[2], 2), vx = jvar(x[3], 3), vy = jvar(x[4], 4),
       r = jvar(x[5], 5), de = jvar(x[6], 6), th = jvar(x[7], 7);
-  jet kap = jlut(T->s_kappa, T->kappa, T->n, s, T->eps_s);                                 /* model.py:66-67 */
+  jet kap = jlut(T->s_kappa, T->kappa, T->n, s, T->eps_s, T->period);                                 /* model.py:66-67 */
   jet cm = jcos(mu), sm = jsin(mu);
   jet sdot = jdiv(jsub(jmul(vx, cm), jmul(vy, sm)), jsub(jconst(1.0), jmul(n, kap))); /* model.py:152 */
   jet Fyf, Fyr;
@@ -249,7 +251,7 @@ static void rhs_jet(const ltompc_params* p, const tables_t* T, const double* x, 
 
 /* value-only rhs (plant, line search) */
 static void rhs_val(const ltompc_params* p, const tables_t* T, const double* x, const double* u, double* f) {
-  double kap = lut_val(T->s_kappa, T->kappa, T->n, x[0], T->eps_s);
+  double kap = lut_val(T->s_kappa, T->kappa, T->n, x[0], T->eps_s, T->period);
   double n = x[1], mu = x[2], vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
   double sdot = (vx * cos(mu) - vy * sin(mu)) / (1.0 - n * kap);
   double af = atan2(vy + p->length_f * r, vx) - de;
@@ -275,7 +277,7 @@ static jet cost_jet(const ltompc_params* p, const tables_t* T, const double* x, 
       de = jvar(x[6], 6);
   jet m = jadd(jadd(jscale(jmul(n, n), p->q_n), jscale(jmul(mu, mu), p->q_mu)), jscale(jmul(vy, vy), p->q_vy));
   if (terminal) return m;
-  jet vref = jlut(T->s_arc, T->v_ref, T->n, s, T->eps_s);
+  jet vref = jlut(T->s_arc, T->v_ref, T->n, s, T->eps_s, T->period);
   jet e = jsub(vx, jscale(vref, p->vref_scale));
   jet bdyn = jatan(jdiv(vy, vx));
   jet bkin = jatan(jscale(de, p->length_r / (p->length_f + p->length_r)));
@@ -285,7 +287,7 @@ static jet cost_jet(const ltompc_params* p, const tables_t* T, const double* x, 
 static double cost_val(const ltompc_params* p, const tables_t* T, const double* x, int terminal) {
   double m = p->q_n * x[1] * x[1] + p->q_mu * x[2] * x[2] + p->q_vy * x[4] * x[4];
   if (terminal) return m;
-  double vref = lut_val(T->s_arc, T->v_ref, T->n, x[0], T->eps_s);
+  double vref = lut_val(T->s_arc, T->v_ref, T->n, x[0], T->eps_s, T->period);
   double e = x[3] - p->vref_scale * vref;
   double db = atan(x[4] / x[3]) - atan(x[6] * p->length_r / (p->length_f + p->length_r));
   return m + p->q_v * e * e + p->q_B * db * db;
@@ -302,14 +304,14 @@ static double cost_val(const ltompc_params* p, const tables_t* T, const double* 
 static void cons_jet(const ltompc_params* p, const tables_t* T, const double* x, jet* g) {
   jet s = jvar(x[0], 0), n = jvar(x[1], 1), mu = jvar(x[2], 2);
   double len = p->length_f + p->length_r, wid = p->width;
-  jet NL = jlut(T->s_arc, T->n_left, T->n, s, T->eps_s), NR = jlut(T->s_arc, T->n_right, T->n, s, T->eps_s);
+  jet NL = jlut(T->s_arc, T->n_left, T->n, s, T->eps_s, T->period), NR = jlut(T->s_arc, T->n_right, T->n, s, T->eps_s, T->period);
   jet sa = jscale(jsinabs(mu, T->eps_mu), 0.5 * len), sp = jscale(jsin(mu), 0.5 * len), cw = jscale(jcos(mu), 0.5 * wid);
   g[0] = jsub(jadd(jsub(n, sa), cw), NL);
   g[1] = jsub(jadd(jsub(sp, n), cw), NR);
   g[2] = jsub(jsub(jsub(cw, sp), n), NR);
 }
 static void cons_val(const ltompc_params* p, const tables_t* T, const double* x, double* g) {
-  double NL = lut_val(T->s_arc, T->n_left, T->n, x[0], T->eps_s), NR = lut_val(T->s_arc, T->n_right, T->n, x[0], T->eps_s);
+  double NL = lut_val(T->s_arc, T->n_left, T->n, x[0], T->eps_s, T->period), NR = lut_val(T->s_arc, T->n_right, T->n, x[0], T->eps_s, T->period);
   double len = p->length_f + p->length_r, wid = p->width;
   double sa = 0.5 * len * sinabs_val(x[2], T->eps_mu), sp = 0.5 * len * sin(x[2]), cw = 0.5 * wid * cos(x[2]);
   g[0] = x[1] - sa + cw - NL;
@@ -1238,8 +1240,9 @@ int oracle_slip_forces(const ltompc_params* p, const double* x, int batch, doubl
 }
 /* plant: classical RK4, n_sub sub-steps, zero-order-hold input (stands in for CVODES at 1e-10) */
 int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const double* x, const double* u,
-                      int batch, double dt, int n_sub, double* xn) {
+                      int batch, double dt, int n_sub, int periodic, double* xn) {
   tables_t T = tables_view(tab, nt);
+  if (periodic) T.period = tab[nt - 1] - tab[0];
   double hs = dt / n_sub;
   for (int b = 0; b < batch; b++) {
     double y[NX], k1[NX], k2[NX], k3[NX], k4[NX], z[NX];
@@ -1269,6 +1272,7 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
   build_bounds(p, &bd0);
   const int ni0 = bd0.ni;
   tables_t T = tables_view(tab, nt);
+  if (o->periodic_tables) T.period = tab[nt - 1] - tab[0];
   (void)nthreads;
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -29,7 +29,7 @@ class Options(C.Structure):
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
         "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("latency_mode", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("latency_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -111,7 +111,7 @@ class Oracle:
         x = np.ascontiguousarray(np.atleast_2d(x), float); u = np.ascontiguousarray(np.atleast_2d(u), float)
         xn = np.zeros_like(x)
         lib().oracle_plant_step(C.byref(self.p), _p(self.tab), self.nt, _p(x), _p(u), x.shape[0],
-                                C.c_double(dt if dt is not None else self.o.t_step), int(n_sub), _p(xn))
+                                C.c_double(dt if dt is not None else self.o.t_step), int(n_sub), int(self.o.periodic_tables), _p(xn))
         return xn
 
     # ---- NLP solve ----------------------------------------------------------------

@@ -521,3 +521,42 @@ def test_other_bound_patterns_use_the_generic_kernels(pkg, tables, orc, gpu_lib)
             assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, mode
             assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9, mode
         mpc.close()
+
+
+def test_periodic_tables_across_the_seam_and_for_more_than_a_lap(pkg, tables, orc, gpu_lib):
+    """options.periodic_tables (closed track): (1) states whose horizon crosses the end of the tables, and the same
+    states one lap further on, against the oracle with the same option; (2) the closed loop (softened track constraints)
+    from s = 700 m through the seam at 857.9 m to s = 1100 m without a failed tick."""
+    L = tables.s_arc[-1] - tables.s_arc[0]
+    B, N = 32, 20
+    x0 = pkg.sample_x0(tables, B, seed=17)
+    x0[:8] = np.concatenate([_midtrack_x0(tables, s) for s in np.linspace(835.0, 857.0, 8)])
+    x0[8:16] = x0[:8]; x0[8:16, 0] += L
+    oo = orc.default_options(); oo.periodic_tables = 1
+    oracle = orc.Oracle(tables.packed(), options=oo)
+    o = pkg.default_options(); o.periodic_tables, o.latency_mode = 1, 2
+    mpc = pkg.BatchedMPC(tables, N, B, options=o)
+    mpc.set_initial_guess(x0)
+    u0 = mpc.make_step(x0)
+    ref = oracle.solve(x0, N, nthreads=8)
+    both = (mpc.status == 0) & (ref["status"] == 0)
+    assert both.mean() > 0.9 and np.abs(u0 - ref["u0"])[both].max() < 1e-5
+    ok = both[:8] & both[8:16]
+    assert ok.sum() >= 6 and np.abs(u0[:8] - u0[8:16])[ok].max() < 1e-7  # one lap further on: the same control
+    X, _ = mpc.prediction()
+    assert X[:8, -1, 0].max() > tables.s_arc[-1]  # (the horizons do cross the seam)
+    xn, xo = mpc.plant_step(x0, ref["u0"]), oracle.plant_step(x0, ref["u0"])
+    assert np.abs(xn - xo).max() < 1e-9
+    mpc.close()
+    # (2)
+    o = pkg.default_options(); o.periodic_tables, o.soft_rho, o.max_iter = 1, 100.0, 300
+    x = _midtrack_x0(tables, 700.0)
+    m1 = pkg.BatchedMPC(tables, 40, 1, options=o)
+    m1.set_initial_guess(x)
+    ticks = 0
+    while x[0, 0] < 1100.0 and ticks < 700:
+        u = m1.make_step(x)
+        assert m1.status[0] in (0, 1), (ticks, x[0, 0], m1.status[0])
+        x = m1.plant_step(x, u, 100); ticks += 1
+    assert x[0, 0] >= 1100.0
+    m1.close()

@@ -164,3 +164,28 @@ def test_soft_track_constraints_solve_where_the_hard_solve_stalls(orc, tables, N
     assert k["soft_violation"] < 1e-3, k
     assert (k["soft_violation"] == 0.0) == (N == 20)
     assert k["objective"] == pytest.approx(r["obj"][0], rel=1e-8, abs=1e-6)
+
+
+def test_periodic_tables_option(orc, tables):
+    """options.periodic_tables (closed track): tables are evaluated at s modulo their span, so a
+    state one lap further on gives the same plant step and the same control; off (the reference: linear extrapolation
+    beyond the last knot) the two differ.  On the first lap the option changes nothing."""
+    L = tables.s_arc[-1] - tables.s_arc[0]
+    x = np.vstack([_midtrack_x0(tables, s) for s in (30.0, 400.0, 845.0)])
+    xl = x.copy(); xl[:, 0] += L
+    o = orc.default_options(); o.periodic_tables = 1
+    per, ref = orc.Oracle(tables.packed(), options=o), orc.Oracle(tables.packed())
+    u = np.tile([[0.2, 0.5]], (3, 1))
+    a, b = per.plant_step(x, u), per.plant_step(xl, u)
+    assert np.abs(b[:, 0] - L - a[:, 0]).max() < 1e-9 and np.abs(b[:, 1:] - a[:, 1:]).max() < 1e-10
+    assert np.array_equal(per.plant_step(x[:2], u[:2]), ref.plant_step(x[:2], u[:2]))  # first lap, away from the seam: identical
+    assert np.abs(ref.plant_step(xl, u)[:, 1:] - a[:, 1:]).max() > 1e-4        # extrapolated tables are a different track
+    N = 20
+    ra, rb = per.solve(x, N, nthreads=3), per.solve(xl, N, nthreads=3)
+    assert np.all(ra["status"] == 0) and np.all(rb["status"] == 0)
+    assert np.abs(ra["u0"] - rb["u0"]).max() < 1e-7 and np.abs(ra["X"][:, :, 1:] - rb["X"][:, :, 1:]).max() < 1e-6
+    assert np.abs(rb["X"][:, :, 0] - L - ra["X"][:, :, 0]).max() < 1e-6
+    # the horizon of the third state crosses the seam (845 m + 20 x 0.1 s x ~9 m/s > 857.9 m)
+    assert ra["X"][2, -1, 0] > tables.s_arc[-1]
+    r0 = ref.solve(x[:2], N, nthreads=2)
+    assert np.abs(r0["u0"] - ra["u0"][:2]).max() < 1e-12
