@@ -216,11 +216,13 @@ __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restri
 
 // ------------------------------------------------------------------------------------------ I/O helpers
 // row-major (B x 8) user buffer -> [8][Bp] planes
-__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm) {
+// (orig != nullptr: the instances are in packed order, slot b holds the caller's instance orig[b])
+__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* __restrict__ orig) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= W.B) return;
+  const size_t r = orig ? orig[b] : b;
 #pragma unroll
-  for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[(size_t)b * 8 + i];
+  for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[r * 8 + i];
   W.si[(size_t)SI_PREV * W.Bp + b] = W.si[(size_t)SI_STATUS * W.Bp + b];  // k_init resets the rest
 }
 __global__ void k_zero_uprev(Work W) {
@@ -229,12 +231,13 @@ __global__ void k_zero_uprev(Work W) {
   W.uprev[b] = 0.0, W.uprev[(size_t)W.Bp + b] = 0.0;
 }
 // u0 = U[:,0,:] -> row-major (B x 2) and u_prev := u0 (do_mpc: _u_prev = last returned u0)
-__global__ void k_store_u0(Work W, double* __restrict__ u0_rm) {
+__global__ void k_store_u0(Work W, double* __restrict__ u0_rm, const int* __restrict__ orig) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= W.B) return;
   const int N = W.N;
+  const size_t r = orig ? orig[b] : b;
   double a = PL(W.U, 0, 0, N), c = PL(W.U, 1, 0, N);
-  if (u0_rm) u0_rm[(size_t)b * 2] = a, u0_rm[(size_t)b * 2 + 1] = c;
+  if (u0_rm) u0_rm[r * 2] = a, u0_rm[r * 2 + 1] = c;
   W.uprev[b] = a, W.uprev[(size_t)W.Bp + b] = c;
 }
 

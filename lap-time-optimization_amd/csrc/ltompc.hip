@@ -48,6 +48,7 @@ struct ltompc_solver {
   int last_compactions = 0;
   int *d_perm = nullptr, *d_orig = nullptr;  // packing: permutation of the current re-packing, original index of every physical slot
   int pack_num = 6;  // re-pack when at most pack_num / 8 of the launch width is still unfinished (LTOMPC_PACK_NUM)
+  bool packed = false;  // the instances are in packed order (d_orig); make_step keeps them so, the accessors restore the caller's order first
   bool packing = true;  // LTOMPC_PACK=0: re-pack the list of unfinished instances only, leave their data where it is
   std::vector<int> history;  // (iteration, n_active, n_launch) triples of the last make_step's polls
   bool cold_next = true;
@@ -162,6 +163,22 @@ int planes_to_host(ltompc_solver* h, const double* dev, int F, int NK, double* o
   for (int b = 0; b < h->B; b++)
     for (int k = 0; k < NK; k++)
       for (int f = 0; f < F; f++) out[((size_t)b * NK + k) * F + f] = tmp[((size_t)f * NK + k) * h->Bp + b];
+  return 0;
+}
+
+
+// Back to the caller's order: slot j returns to orig[j].  make_step leaves the instances in the order of its last
+// re-packing (it only maps x0 in and u0 out through `orig`); everything that exposes per-instance arrays calls this first.
+int ensure_unpacked(ltompc_solver* h) {
+  if (!h->packed) return 0;
+  const int B = h->B, N = h->N;
+  hipLaunchKernelGGL(k_pack_inverse, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
+  const int nthreads = (N + 1) * B;
+  for (int pass = 0; pass < 2; pass++)
+    hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, (const int*)nullptr, B, h->d_orig,
+                       h->K.bd.ni, pass);
+  HIPCHECK(hipGetLastError());
+  h->packed = false;
   return 0;
 }
 
@@ -363,7 +380,8 @@ int ltompc_set_poll_every(ltompc_handle h, int n) {
 int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev) {
   if (!h || !x0_dev) return fail("ltompc_set_initial_guess: null argument");
   HIPCHECK(hipSetDevice(h->device));
-  hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
+  h->packed = false;  // a cold start overwrites the whole iterate: nothing to restore
+  hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)nullptr);
   hipLaunchKernelGGL(k_zero_uprev, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W);
   hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, 1);
   HIPCHECK(hipGetLastError());
@@ -386,7 +404,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   HIPCHECK(hipSetDevice(h->device));
   const int B = h->B, N = h->N, Bp = h->Bp;
   Launcher L{h};
-  hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev);
+  hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)(h->packed ? h->d_orig : nullptr));
   if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
   if (!h->cold_next && h->K.o.warm_shift) {
     hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 0);
@@ -409,7 +427,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   h->last_compactions = 0;
   h->history.clear();
   int it = 0;
-  bool packed_any = false, force_eval_next = false;
+  bool force_eval_next = false;
   for (;; it++) {
     const int np = la.n_pad;
     la.force_eval = force_eval_next ? 1 : 0;
@@ -451,11 +469,11 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       if (n_active == 0) break;
       if (h->compaction && n_active <= (h->pack_num * n_launch) / 8) {
         // finished instances only idle inside a launch, but they keep whole wavefronts alive: re-pack
-        if (h->packing) {
+        if (h->packing && n_launch > 512) {  // (narrow launches run one wavefront or workgroup per instance: nothing to coalesce)
           // ... the instances themselves (the first nact slots are permuted, unfinished ones first; k_pack in
           // aux_kernels.h), so that the lanes of a wavefront keep touching neighbouring addresses
-          if (!packed_any) hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
-          packed_any = true;
+          if (!h->packed) hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
+          h->packed = true;
           hipLaunchKernelGGL(k_pack_perm, dim3(1), dim3(1024), 0, h->stream, h->d_nact[cur], h->W.si + (size_t)SI_DONE * Bp, h->d_perm,
                              h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
           const int nthreads = (N + 1) * n_launch;
@@ -474,14 +492,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     }
   }
   if (L.close()) return -1;
-  if (packed_any) {  // back to the caller's order: slot j returns to orig[j]
-    hipLaunchKernelGGL(k_pack_inverse, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, B);
-    const int nthreads = (N + 1) * B;
-    for (int pass = 0; pass < 2; pass++)
-      hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, (const int*)nullptr, B, h->d_orig,
-                         h->K.bd.ni, pass);
-  }
-  hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev);
+  hipLaunchKernelGGL(k_store_u0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, u0_dev, (const int*)(h->packed ? h->d_orig : nullptr));
   HIPCHECK(hipGetLastError());
   h->last_launches = L.launches + 3;
   h->last_iterations = it + 1;
@@ -495,6 +506,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
 int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error, double* objective, double* mu) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
   std::vector<int> si((size_t)SI_NF * h->Bp);
   std::vector<double> st((size_t)ST_NF * h->Bp);
   HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -513,6 +525,7 @@ int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error
 int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
   std::vector<int> si((size_t)SI_NF * h->Bp);
   HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
@@ -540,6 +553,7 @@ int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status,
 int ltompc_get_prediction(ltompc_handle h, double* X, double* U) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
   if (planes_to_host(h, h->W.X, 8, h->N + 1, X)) return -1;
   return planes_to_host(h, h->W.U, 2, h->N, U);
 }
@@ -547,6 +561,7 @@ int ltompc_get_prediction(ltompc_handle h, double* X, double* U) {
 int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double* L1, double* L2) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
   if (planes_to_host(h, h->W.X, 8, h->N + 1, X)) return -1;
   if (planes_to_host(h, h->W.C, 8, h->N, C)) return -1;
   if (planes_to_host(h, h->W.U, 2, h->N, U)) return -1;
@@ -557,6 +572,7 @@ int ltompc_get_iterate(ltompc_handle h, double* X, double* C, double* U, double*
 int ltompc_get_ineq(ltompc_handle h, double* T, double* NU, int* n_ineq) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
   if (n_ineq) *n_ineq = h->K.bd.ni;
   if (planes_to_host(h, h->W.T, h->K.bd.ni, h->N, T)) return -1;
   return planes_to_host(h, h->W.NU, h->K.bd.ni, h->N, NU);
@@ -632,6 +648,7 @@ int ltompc_get_history(ltompc_handle h, int* triples, int capacity) {
 // 7 dC, 8 dT, 9 dNU, 10 nL1, 11 nL2, 12 st, 13 si (ints).  Returns the number of bytes of the array (copies min(nbytes, size)).
 long long ltompc_debug_fetch(ltompc_handle h, int which, void* out, long long nbytes) {
   if (!h) return fail("null handle");
+  if (hipSetDevice(h->device) != hipSuccess || ensure_unpacked(h)) return fail("ltompc_debug_fetch: could not restore the caller's order");
   const size_t N = h->N, Bp = h->Bp, ni = h->K.bd.ni;
   const Work& W = h->W;
   const void* src[15] = {W.QP, W.RC, W.RS, W.SP, W.LS, W.dX, W.dU, W.dC, W.dT, W.dNU, W.nL1, W.nL2, W.st, W.si, W.DBG};

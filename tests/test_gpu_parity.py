@@ -560,3 +560,33 @@ def test_periodic_tables_across_the_seam_and_for_more_than_a_lap(pkg, tables, or
         x = m1.plant_step(x, u, 100); ticks += 1
     assert x[0, 0] >= 1100.0
     m1.close()
+
+
+def test_packed_order_is_kept_between_ticks_and_invisible(pkg, tables, gpu_lib):
+    """Between two make_steps the instances stay in the order of the last re-packing (only x0 in and u0 out are mapped);
+    the accessors restore the caller's order.  A loop on device pointers with no accessor in between (what bench.py
+    times) gives bit-identical controls, statuses and predictions to a loop that reads the statistics after every tick."""
+    import torch
+    B, N = 2048, 10
+    x0 = pkg.sample_x0(tables, B, seed=23)
+    dev = torch.device("cuda", 0)
+    a, b = pkg.BatchedMPC(tables, N, B), pkg.BatchedMPC(tables, N, B)
+    a.set_initial_guess(x0); b.set_initial_guess(x0)
+    xa = torch.from_numpy(x0).to(dev); xn = torch.empty_like(xa); ua = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    a.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    xb = x0.copy()
+    for tick in range(4):
+        a.make_step_dev(xa.data_ptr(), ua.data_ptr())
+        a.plant_step_dev(xa.data_ptr(), ua.data_ptr(), xn.data_ptr(), 50)
+        xa, xn = xn, xa
+        ub = b.make_step(xb)          # (reads status / iterations: restores the caller's order every tick)
+        xb = b.plant_step(xb, ub, 50)
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(ua.cpu().numpy(), ub), tick
+        assert np.array_equal(xa.cpu().numpy(), xb), tick
+    sa, sb = a.stats(), b.stats()
+    assert np.array_equal(sa["status"], sb["status"]) and np.array_equal(sa["iters"], sb["iters"]) and np.array_equal(sa["kkt"], sb["kkt"])
+    Xa, Ua = a.prediction(); Xb, Ub = b.prediction()
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
+    assert max(h[2] for h in a.history()) == B and min(h[2] for h in a.history()) < B // 2  # (the solve did re-pack)
+    a.close(); b.close()
