@@ -76,6 +76,11 @@ __device__ __forceinline__ void lut_eval(const double* __restrict__ grid, const 
   int im = i > 0 ? i - 1 : 0, ip = i + 2 < n ? i + 2 : n - 1;
   double gm = grid[im], gi = grid[i], gi1 = grid[i + 1], gp = grid[ip];
   double ym = y[im], yi = y[i], yi1 = y[i + 1], yp = y[ip];
+#if defined(__HIP_DEVICE_COMPILE__)
+  // all eight values in registers HERE: otherwise the compiler sinks the loads into the (short-circuit) test below
+  // and the branches after it, and the look-up is a chain of dependent round trips again
+  asm volatile("" : "+v"(gm), "+v"(gi), "+v"(gi1), "+v"(gp), "+v"(ym), "+v"(yi), "+v"(yi1), "+v"(yp));
+#endif
   if ((i > 0 && s < gi) || (i < n - 2 && s >= gi1)) {
     while (i > 0 && s < grid[i]) --i;
     while (i < n - 2 && s >= grid[i + 1]) ++i;
