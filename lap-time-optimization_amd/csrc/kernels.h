@@ -4,7 +4,8 @@
 // iterations, each a fixed sequence of kernels over the instances that have not finished:
 //
 //   layout.h      buffers, field indices, Work / Launch / Consts, wave-level helpers
-//   linearise.h   k_eval    thread = (interval k, instance b): derivatives of dynamics / cost / constraints at the
+//   linearise.h   (kernels instantiated for the reference's bound pattern, BoundsRef, and for a run-time pattern)
+//                 k_eval    thread = (interval k, instance b): derivatives of dynamics / cost / constraints at the
 //                           Radau point and the next node, KKT-residual partials, block-structured elimination of the
 //                           collocation variables -> stage QP blocks (A, B, b, Q, S, R, q, r)
 //                 k_expand  thread = (k, b): collocation steps and multipliers, slack / inequality-multiplier steps,
@@ -15,7 +16,8 @@
 //                 backward sweep with inertia-correcting regularisation, forward rollout
 //   linesearch.h  k_linesearch (filter measures of the step candidates), k_pick (filter test, step length, stall
 //                 bookkeeping), k_update (z += alpha dz), k_step1 (the three fused, one workgroup per instance)
-//   aux_kernels.h k_init, k_shift, k_compact, I/O, k_plant (RK4 plant step), test hooks
+//   aux_kernels.h k_init, k_shift, re-packing of the unfinished instances (k_pack_perm / k_pack move their data to the
+//                 front of the batch, k_compact re-packs the index list only), I/O, k_plant (RK4 plant step), test hooks
 #pragma once
 #include "layout.h"
 #include "linearise.h"

@@ -187,7 +187,7 @@ int ensure_unpacked(ltompc_solver* h) {
 extern "C" {
 
 const char* ltompc_last_error(void) { return g_err.c_str(); }
-const char* ltompc_version(void) { return "ltompc 0.3 (gfx950, fp64; block-structured interval evaluation, LDS-staged wave-cooperative Riccati)"; }
+const char* ltompc_version(void) { return "ltompc 0.4 (gfx950, fp64; block-structured interval evaluation, LDS-staged wave-cooperative Riccati, data re-packing)"; }
 
 void ltompc_default_params(ltompc_params* p) {
   std::memset(p, 0, sizeof *p);
