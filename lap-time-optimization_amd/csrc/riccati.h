@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
         ok = false;
         break;
       }
-      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      const double idet = 1.0 / det;  // one division per stage instead of four (same expression in the three Riccati kernels)
+      double Hi[4] = {Huu[3] * idet, -Huu[1] * idet, -Huu[2] * idet, Huu[0] * idet};
       double Kx[16], Kv[4], kff[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
@@ -488,7 +489,8 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
       bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
       if (bad && live) ok = false;
       if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;  // keep the lock-step arithmetic finite
-      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      const double idet = 1.0 / det;  // one division per stage instead of four (same expression in the three Riccati kernels)
+      double Hi[4] = {Huu[3] * idet, -Huu[1] * idet, -Huu[2] * idet, Huu[0] * idet};
       double Kc[2], Kv[4], kff[2];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
@@ -878,7 +880,8 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
       if (bad && live) ok = false;
       if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;
-      double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
+      const double idet = 1.0 / det;  // one division per stage instead of four (same expression in the three Riccati kernels)
+      double Hi[4] = {Huu[3] * idet, -Huu[1] * idet, -Huu[2] * idet, Huu[0] * idet};
       double Kc[2], Kv[4], kff[2];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
