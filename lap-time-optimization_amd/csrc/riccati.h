@@ -527,8 +527,10 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
       vk[0] = k > 1 ? vn0 : up0, vk[1] = k > 1 ? vn1 : up1;
       if (live) {
         PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
-        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
-        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        // (selected, not indexed: a register array indexed by the lane's row lives in scratch memory, and a scratch reload
+        //  waits for the global stores issued before it - vmcnt counts both)
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = i == 0 ? Kv[0] : (i == 1 ? Kv[1] : (i == 2 ? Kv[2] : Kv[3]));
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = i == 0 ? kff[0] : kff[1];
         if (k > 0) {
 #pragma unroll
           for (int j = 0; j < 8; j++)
@@ -914,8 +916,10 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       }
       if (live) {
         PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
-        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = Kv[i];
-        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = kff[i];
+        // (selected, not indexed: a register array indexed by the lane's row lives in scratch memory, and a scratch reload
+        //  waits for the global stores issued before it - vmcnt counts both)
+        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = i == 0 ? Kv[0] : (i == 1 ? Kv[1] : (i == 2 ? Kv[2] : Kv[3]));
+        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = i == 0 ? kff[0] : kff[1];
         if (k > 0) {
 #pragma unroll
           for (int j = 0; j < 8; j++)
