@@ -263,9 +263,10 @@ __global__ void __launch_bounds__(64) k_pick(const Consts* __restrict__ Kp, cons
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
-  const int j = blockIdx.x * 8 + g;
-  if (j >= (phase == 0 ? la.nact[0] : W.ls_count[0])) return;
-  d_pick(K, W, phase == 0 ? la.act[j] : W.ls_list[j], i, phase, true);
+  const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
+  // (phase 1 is launched for the expected length of the list of rejected steps, longer lists are covered grid-stride;
+  //  the 8 lanes of an instance stay together)
+  for (int j = blockIdx.x * 8 + g; j < count; j += gridDim.x * 8) d_pick(K, W, phase == 0 ? la.act[j] : W.ls_list[j], i, phase, true);
 }
 
 // ------------------------------------------------------------------------------------------ k_update
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, co
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  if (tid == 0) W.ls_count[0] = 0;  // both line-search phases of this iteration are over
+  if (tid == 0) W.ls_count[1] = W.ls_count[0], W.ls_count[0] = 0;  // both line-search phases of this iteration are over ([1]: the host sizes the next phase-1 launches by it)
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
   d_update(K, W, k, la.act[j]);

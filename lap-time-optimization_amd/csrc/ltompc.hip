@@ -47,6 +47,7 @@ struct ltompc_solver {
   int *d_act[2] = {nullptr, nullptr}, *d_nact[2] = {nullptr, nullptr};  // ping-pong lists of unfinished instances
   int last_compactions = 0;
   int *d_perm = nullptr, *d_orig = nullptr;  // packing: permutation of the current re-packing, original index of every physical slot
+  int ls_width_env = 0;  // LTOMPC_LSW: fixed launch width (instances) of the second line-search phase (0: sized by the last list)
   int pack_num = 6;  // re-pack when at most pack_num / 8 of the launch width is still unfinished (LTOMPC_PACK_NUM)
   bool packed = false;  // the instances are in packed order (d_orig); make_step keeps them so, the accessors restore the caller's order first
   bool packing = true;  // LTOMPC_PACK=0: re-pack the list of unfinished instances only, leave their data where it is
@@ -255,6 +256,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     h->compaction = !(c && std::string(c) == "0");
     const char* pk = getenv("LTOMPC_PACK");
     h->packing = !(pk && std::string(pk) == "0");
+    const char* lw = getenv("LTOMPC_LSW");
+    if (lw && atoi(lw) >= 64) h->ls_width_env = atoi(lw);
     const char* pn = getenv("LTOMPC_PACK_NUM");
     if (pn && atoi(pn) >= 1 && atoi(pn) <= 7) h->pack_num = atoi(pn);
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
@@ -412,7 +415,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   }
   hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
-  HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, sizeof(int), h->stream));
+  HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, 2 * sizeof(int), h->stream));
   h->cold_next = false;
   // all instances unfinished: identity list
   int cur = 0, n_launch = B;
@@ -428,6 +431,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   h->history.clear();
   int it = 0;
   bool force_eval_next = false;
+  int ls_width = h->ls_width_env ? h->ls_width_env : 512;  // until the first poll of this solve
   for (;; it++) {
     const int np = la.n_pad;
     la.force_eval = force_eval_next ? 1 : 0;
@@ -454,17 +458,26 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
       if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
       if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
-        const int jw = np < 512 ? np : 512;  // rejected full steps are ~3% of the instances
+        const int jw = np < ls_width ? np : ls_width;  // launch width of the second phase (longer lists are covered grid-stride)
         if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
-        if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 1)) return -1;
+        if (L.run(4, k_pick, jw * 8, h->d_K, h->d_W, la, 1)) return -1;
       }
       if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;
     }
     if ((it + 1) % h->poll_every == 0) {
       if (L.close()) return -1;
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
       const int n_active = h->h_active[0];  // instances that passed the termination test of iteration `it`
+      // Second line-search phase: one thread per (candidate, interval, rejected instance).  Its launch costs in
+      // proportion to its width whether the threads find work or not (measured: 52 us at 192 instances, 130 us at 512,
+      // 358 us at 2048, for ~250 rejected instances), and a list longer than the width costs whole extra passes: sized
+      // by the length of the last list, with a margin.
+      if (h->ls_width_env == 0) {
+        const int last = h->h_active[1];
+        ls_width = std::min(std::max(64, (last + last / 2 + 63) / 64 * 64), 2048);
+      }
       h->history.push_back(it), h->history.push_back(n_active), h->history.push_back(n_launch);
       if (n_active == 0) break;
       if (h->compaction && n_active <= (h->pack_num * n_launch) / 8) {
