@@ -138,24 +138,27 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   a_pri = grp_min(a_pri), a_dua = grp_min(a_dua), gphid = grp_sum(gphid);
   // lterm(x_0) is a constant of the solve; kept so that phi matches the oracle's barrier objective
   const double c00 = STD(ST_C00);
-  auto measures = [&](int l, double& th, double& ph) {
-    double t = 0.0, c = 0.0, s = 0.0;
+  // filter measures of candidates lA and lB (sums over the horizon of the partials written by k_eval / k_linesearch): the
+  // loads of both go out together, a pair of candidates costs one round trip per 32 stages
+  auto measures2 = [&](int lA, int lB, double& thA, double& phA, double& thB, double& phB) {
+    double tA = 0.0, cA = 0.0, sA = 0.0, tB = 0.0, cB = 0.0, sB = 0.0;
     for (int k0 = i; k0 < N; k0 += 32) {
-      double v[3][4];
+      double v[6][4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int k = k0 + 8 * q < N ? k0 + 8 * q : k0;
-        v[0][q] = PL(W.LS, 3 * l + 0, k, N), v[1][q] = PL(W.LS, 3 * l + 1, k, N), v[2][q] = PL(W.LS, 3 * l + 2, k, N);
+        v[0][q] = PL(W.LS, 3 * lA + 0, k, N), v[1][q] = PL(W.LS, 3 * lA + 1, k, N), v[2][q] = PL(W.LS, 3 * lA + 2, k, N);
+        v[3][q] = PL(W.LS, 3 * lB + 0, k, N), v[4][q] = PL(W.LS, 3 * lB + 1, k, N), v[5][q] = PL(W.LS, 3 * lB + 2, k, N);
       }
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        if (k0 + 8 * q < N) t += v[0][q], c += v[1][q], s += v[2][q];
+        if (k0 + 8 * q < N) tA += v[0][q], cA += v[1][q], sA += v[2][q], tB += v[3][q], cB += v[4][q], sB += v[5][q];
     }
-    t = grp_sum(t), c = grp_sum(c), s = grp_sum(s);
-    th = t, ph = (c00 + c) - mu * s;
+    tA = grp_sum(tA), cA = grp_sum(cA), sA = grp_sum(sA), tB = grp_sum(tB), cB = grp_sum(cB), sB = grp_sum(sB);
+    thA = tA, phA = (c00 + cA) - mu * sA, thB = tB, phB = (c00 + cB) - mu * sB;
   };
-  double th0, ph0;
-  measures(0, th0, ph0);
+  double th0, ph0, th1, ph1;
+  measures2(0, 1, th0, ph0, th1, ph1);  // the current point and the full step
   double theta0 = STD(ST_THETA0);
   int nfilt = STI(SI_NFILT);
   double theta_max = STD(ST_THMAX), theta_min = STD(ST_THMIN);
@@ -169,23 +172,22 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   double alpha = a_pri;
   const int n_ls = o.n_linesearch;
   const int n_try = (phase == 0) ? 1 : n_ls;  // phase 1 repeats the test of candidate 0 (same outcome) and goes on
-  for (int l = 0; l < n_try; l++, alpha *= 0.5) {
-    double th, ph;
-    measures(l + 1, th, ph);
-    if (!isfinite(th) || !isfinite(ph) || th > theta_max) continue;
+  // the filter (at most FILTER_MAX pairs) once, in registers: it only changes when a candidate is accepted
+  double fth[FILTER_MAX], fph[FILTER_MAX];
+#pragma unroll
+  for (int f = 0; f < FILTER_MAX; f++) fth[f] = W.filt[(size_t)(2 * f) * W.Bp + b], fph[f] = W.filt[(size_t)(2 * f + 1) * W.Bp + b];
+  auto try_candidate = [&](const double th, const double ph) -> bool {  // true: accepted (filter updated)
+    if (!isfinite(th) || !isfinite(ph) || th > theta_max) return false;
     bool in_filter = false;
-    for (int f = 0; f < nfilt; f++)
-      if (th >= W.filt[(size_t)(2 * f) * W.Bp + b] && ph >= W.filt[(size_t)(2 * f + 1) * W.Bp + b]) {
-        in_filter = true;
-        break;
-      }
-    if (in_filter) continue;
+#pragma unroll
+    for (int f = 0; f < FILTER_MAX; f++) in_filter = in_filter || (f < nfilt && th >= fth[f] && ph >= fph[f]);
+    if (in_filter) return false;
     bool sw = (gphid < 0.0) && (alpha * pow(-gphid, s_ph) > dlt * pow(th0, s_th));
     bool armijo = ph <= ph0 + eta_ph * alpha * gphid;
     bool ok;
     if (th0 <= theta_min && sw) ok = armijo;
     else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
-    if (!ok) continue;
+    if (!ok) return false;
     if (!(sw && armijo)) {  // augment the filter (written by lane i == 0, nobody reads it again in this launch)
       if (nfilt == FILTER_MAX) {
         if (i == 0)
@@ -201,8 +203,22 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
       }
       nfilt++;
     }
-    accepted = true;
-    break;
+    return true;
+  };
+  // candidate l + 1 has alpha = a_pri 2^-l; candidates are measured in pairs (the first one came with the current point)
+  accepted = try_candidate(th1, ph1);
+  if (!accepted) alpha *= 0.5;
+  for (int l = 1; l < n_try && !accepted; l += 2) {
+    double thA, phA, thB, phB;
+    measures2(l + 1, l + 2 <= n_ls ? l + 2 : l + 1, thA, phA, thB, phB);
+    accepted = try_candidate(thA, phA);
+    if (!accepted) {
+      alpha *= 0.5;
+      if (l + 1 < n_try) {
+        accepted = try_candidate(thB, phB);
+        if (!accepted) alpha *= 0.5;
+      }
+    }
   }
   if (i != 0) return;  // one writer per instance from here on
   if (phase == 0) {
