@@ -94,7 +94,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
 }
 
 template <class BP>
-__global__ void __launch_bounds__(64, 2) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
+__global__ void __launch_bounds__(64) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   // phase 0: thread = (k, j), evaluates the first candidate (full step to the boundary) of instance act[j].
