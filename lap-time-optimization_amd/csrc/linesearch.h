@@ -12,7 +12,7 @@ namespace ltompc {
 // for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
 // Filter measures (theta, cost, sum log t) of the step candidates l_begin..l_end of interval k of instance b;
 // candidate l >= 1 has alpha = a_pri * 2^-(l-1) (l = 0, the current point, is written by k_eval).
-template <class BP>
+template <class BP, bool PIN>
 __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, const int k, const int b, const int l_begin,
                                              const int l_end) {
   const int N = W.N;
@@ -65,7 +65,22 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
     // sum of log t as the log of products of 8 slacks (same grouping in linearise_slot): 3 logarithms instead of 23
     double sl = 0.0, pr = 1.0;
     double tt[BP::fixed ? MAX_NI : 1];  // compile-time bound pattern: the slacks of the candidate in one batch of loads
-    if (BP::fixed) for_each_bound<BP>(K.p, [&](int mm, int, int, double, double) { tt[mm] = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N); });
+    if (BP::fixed) {
+      double t0[MAX_NI], d0[MAX_NI];
+      const int nb = for_each_bound<BP>(K.p, [&](int mm, int, int, double, double) { t0[mm] = PL(W.T, mm, k, N), d0[mm] = PL(W.dT, mm, k, N); });
+      // (all of them in registers before the first use: left alone the compiler issues and awaits them pair by pair)
+#pragma unroll
+      for (int q = 0; q < MAX_NI; q += 8)
+        if (PIN && q < nb) {  // (k_step1, two wavefronts per SIMD, is faster without: fewer registers)
+          double* a = t0 + q;
+          double* c = d0 + q;
+          asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                            "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        }
+#pragma unroll
+      for (int q = 0; q < MAX_NI; q++)
+        if (q < nb) tt[q] = t0[q] + alpha * d0[q];
+    }
     const int m = for_each_bound<BP>(K.p, [&](int mm, int kind, int jj, double sg, double val) {
       const double xv = kind == 0 ? tu[jj] : (kind == 1 ? tc[jj] : txp[jj]);
       const double t = BP::fixed ? tt[mm] : PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
@@ -106,7 +121,7 @@ __global__ void __launch_bounds__(64) k_linesearch(const Consts* __restrict__ Kp
   if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
   const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
   const int l = phase == 0 ? 1 : 2 + cand;
-  for (int j = j0; j < count; j += jw) d_linesearch<BP>(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
+  for (int j = j0; j < count; j += jw) d_linesearch<BP, true>(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
 }
 
 // ------------------------------------------------------------------------------------------ k_pick
@@ -336,7 +351,7 @@ __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, co
   if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
   // all step candidates at once (the threads are there anyway; the wide path evaluates candidates 2.. only for the
   // instances that rejected the full step, with the same arithmetic)
-  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
+  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP, false>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
   __syncthreads();
   if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
   __syncthreads();
