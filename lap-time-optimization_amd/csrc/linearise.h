@@ -171,13 +171,24 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   S.m_nl = m_nl;
   S.nl = (k + 1 <= N - 1);  // nl_cons are checked at nodes 1..N-1 (node 0 is data, node N is not checked)
   if (S.nl) {
+    // slacks / multipliers (/ elastic variables, stored after the slacks) of the three track constraints: fetched
+    // together, before the constraint evaluation with its two table look-ups
+    double tq[3], nq[3], eq[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      tq[q] = PL(W.T, m_nl + q, k, N), nq[q] = PL(W.NU, m_nl + q, k, N);
+      eq[q] = rho > 0.0 ? PL(W.T, m_nl + 3 + q, k, N) : 0.0;
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(nq[0]), "+v"(nq[1]), "+v"(nq[2]), "+v"(eq[0]), "+v"(eq[1]), "+v"(eq[2]));
+#endif
     double hss[3], hmm[3];
     cons_eval(K.p, K.T, eps, S.xp, S.gv, S.gs, S.gn, S.gm, hss, hmm);
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       int mm = m_nl + q;
-      double t = PL(W.T, mm, k, N), nu = PL(W.NU, mm, k, N);
-      const double e = rho > 0.0 ? PL(W.T, mm + 3, k, N) : 0.0;  // soft: elastic variable, stored after the slacks
+      double t = tq[q], nu = nq[q];
+      const double e = eq[q];
       double Sg, s0, s1;
       track_barrier(rho, S.gv[q], t, nu, e, Sg, s0, s1);
       double g3[3] = {S.gs[q], S.gn[q], S.gm[q]};
