@@ -353,12 +353,10 @@ __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, co
   // instances that rejected the full step, with the same arithmetic)
   for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP, false>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
   __syncthreads();
-  if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 0, false);
+  // (phase 1 of the filter test starts with the test of the full step, i.e. it is phase 0 followed by phase 1 when the
+  //  measures of all candidates exist already: one pass, same decisions)
+  if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
   __syncthreads();
-  if (si[(size_t)SI_LSMORE * W.Bp + b]) {  // block-uniform (written before the barrier)
-    if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
-    __syncthreads();
-  }
   for (int kk = tid; kk < N; kk += 320) d_update(K, W, kk, b);
 }
 
