@@ -50,6 +50,19 @@ def test_controller_argument_checks(pkg):
         pkg.Controller(model, np.array([1e-2, 1e-2]))
     with pytest.raises(NotImplementedError):
         pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)), n_robust=1)
+    with pytest.raises(ValueError):  # do_mpc's set_nl_cons(soft_constraint=True, penalty_term_cons=...) needs a positive penalty
+        pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)), soft_constraint=True, penalty_term_cons=0.0)
+
+
+def test_options_struct_matches_the_header(pkg, orc):
+    """Field order of ltompc_options: the two ctypes mirrors (product, oracle) against include/ltompc.h."""
+    import os, re
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "ltompc.h")).read()
+    body = hdr[hdr.index("typedef struct ltompc_options {"):hdr.index("} ltompc_options;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:double|int)\s+(\w+)\s*;", body)
+    assert fields == [n for n, _ in pkg.Options._fields_] == [n for n, _ in orc.Options._fields_]
+    assert "soft_rho" in fields and "periodic_tables" in fields
 
 
 def test_scenarios_are_deterministic_and_feasible(pkg, tables, oracle):
