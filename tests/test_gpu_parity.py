@@ -195,6 +195,17 @@ def test_gpu_error_behaviour(pkg, tables, gpu_lib):
     assert np.array_equal(u0[0], u0[2])
     with pytest.raises(pkg.LtompcError):
         pkg.BatchedMPC(tables, 1, 4)                    # horizon out of range
+    o = pkg.default_options(); o.soft_rho = -1.0
+    with pytest.raises(pkg.LtompcError):
+        pkg.BatchedMPC(tables, 10, 4, options=o)        # the penalty of softened track constraints must be >= 0
+    # with softened track constraints the far-off-track instance is not a failure any more
+    o.soft_rho = 100.0
+    ms = pkg.BatchedMPC(tables, 10, 4, options=o)
+    ms.set_initial_guess(x)
+    us = ms.make_step(x)
+    assert np.all(np.isfinite(us)) and np.all(ms.status[[0, 2, 3]] == 0)
+    assert np.abs(us[[0, 2, 3]] - u0[[0, 2, 3]]).max() < 1e-6   # (exact penalty: the feasible instances do not change)
+    ms.close()
     mpc.close()
 
 
