@@ -36,8 +36,12 @@ extern "C" {
 #define LTOMPC_STATUS_ACCEPTABLE 1      /* <= acceptable_tol for acceptable_iter iterations       */
 #define LTOMPC_STATUS_MAX_ITER 2        /* iteration budget exhausted, last iterate returned      */
 #define LTOMPC_STATUS_NUMERICAL 3       /* non-finite value / regularisation overflow             */
-#define LTOMPC_STATUS_STALLED 4         /* no progress (locally infeasible problem): IPOPT would report
-                                           'restoration failed / local infeasibility'             */
+#define LTOMPC_STATUS_STALLED 4         /* no progress and the restoration phase could not help (or is
+                                           switched off): IPOPT's 'restoration failed'              */
+#define LTOMPC_STATUS_INFEASIBLE 5      /* the restoration phase converged to a stationary point of the
+                                           constraint violation with violation > 0: the horizon problem is
+                                           locally infeasible (IPOPT: 'converged to a point of local
+                                           infeasibility'); the least-violation iterate is returned    */
 
 /* Vehicle + objective + bounds.  Defaults (ltompc_default_params) are the values the reference
  * actually uses, including its quirks: D_f = D_r = 1.0 because model.py:42-64
@@ -89,6 +93,14 @@ typedef struct ltompc_options {
    * soft_rho = 100 all 769 ticks of the buckmore lap converge.  The elastic variables are eliminated
    * with the slacks: same stage-QP sizes, same kernels, three more planes per interval. */
   double soft_rho;        /* 0 */
+  /* Restoration phase (what IPOPT enters when its filter line search fails).  Here it is an ELASTIC mode:
+   * the solve is continued on the same NLP with every track constraint relaxed by an elastic variable e >= 0 that
+   * costs resto_rho * e (the machinery of soft_rho, with IPOPT's restoration penalty 1000), the barrier parameter and
+   * the slacks re-centred.  When the elastic problem has converged with all e <= tol the iterate is a KKT point of the
+   * hard-constrained NLP: the solve switches back to the hard constraints and terminates there (status SOLVED);
+   * with some e > tol the problem is locally infeasible (status INFEASIBLE).  0 = no restoration: a failed line
+   * search ends the solve with status STALLED after max_ls_fail attempts, as in round 1. */
+  double resto_rho;       /* 1000 */
   int max_iter;           /* controller.py:18 says 1000 */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
@@ -106,6 +118,11 @@ typedef struct ltompc_options {
                              closed loop, tables are evaluated at s modulo their span (buckmore: kappa, n_left, n_right
                              agree at both ends, v_ref to 0.2 %), so that the closed loop can run lap after lap; the kink
                              at the seam is not rounded                                      (0) */
+  int max_soc;            /* second-order corrections per iteration (IPOPT's max_soc): when the full step is rejected and
+                             does not reduce the constraint violation, the step is re-computed with the constraint
+                             residuals of the trial point added (same KKT matrix, new right-hand side: a Riccati sweep
+                             over the vectors only).  Implemented in the oracle, where it was measured not to change
+                             the iteration counts of this NLP; the device library accepts 0 only    (0) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),
@@ -182,6 +199,11 @@ int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev);
 
 /* Per-instance counters of the last solve: Hessian-regularisation retries, failed line searches (host, out). */
 int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
+
+/* Restoration phase of the last solve (host, out; any may be NULL): how often an instance entered it (0 or 1), and the
+ * largest elastic variable at termination, i.e. the remaining violation of the track constraints in metres (> tol for
+ * status INFEASIBLE; 0 for instances that ended on the hard constraints). */
+int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation);
 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:

@@ -10,7 +10,7 @@ from ._build import LIB
 
 NX, NU = 8, 2
 NO_BOUND = 1.0e30
-STATUS_NAMES = {0: "solved", 1: "acceptable", 2: "max_iter", 3: "numerical", 4: "stalled"}
+STATUS_NAMES = {0: "solved", 1: "acceptable", 2: "max_iter", 3: "numerical", 4: "stalled", 5: "infeasible"}
 
 
 class Params(C.Structure):
@@ -26,9 +26,9 @@ class Options(C.Structure):
     """ltompc_options (include/ltompc.h)."""
     _fields_ = [(n, C.c_double) for n in (
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
-        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho")] + [
+        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho", "resto_rho")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("latency_mode", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("latency_mode", C.c_int)]
 
 
 class LtompcError(RuntimeError):

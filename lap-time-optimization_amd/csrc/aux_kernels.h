@@ -43,27 +43,8 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
   const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
-  // (flat visitor, no nested by-reference lambdas: see d_expand)
-  const int m = for_each_bound<BoundsAny>(K.p, [&](int mm, int kind, int j, double sg, double val) {
-    const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
-    const double hv = sg * (xv - val);
-    const double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
-    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
-  });
-  double gv[3] = {-1.0, -1.0, -1.0};
-  if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
-  for (int q = 0; q < 3; q++) {
-    double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push, e = 0.0;
-    if (K.o.soft_rho > 0.0) {
-      // softened: slack and multiplier as for the hard constraint (a violated constraint starts as an infeasibility of
-      // g - e + t = 0 that the Newton steps remove, not as a large elastic variable with nu ~ rho that the barrier lets
-      // go of only slowly); the elastic variable on the central path of its own pair, e (rho - nu) = mu.
-      // t >= 2 mu / rho keeps nu <= rho / 2.
-      t = fmax(t, 2.0 * mu / K.o.soft_rho);
-      e = mu / (K.o.soft_rho - mu / t);
-    }
-    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;
-  }
+  const double rho = K.o.soft_rho;  // (the restoration phase replaces it per instance, see d_pick)
+  init_slot_slacks<BoundsAny>(K, W, k, b, mu, eps, rho, xp, c, u);
   if (k == 0) {
     double* st = W.st;
     st[(size_t)ST_MU * W.Bp + b] = mu, st[(size_t)ST_EPS * W.Bp + b] = eps, st[(size_t)ST_EPS_NEXT * W.Bp + b] = eps;
@@ -73,6 +54,7 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
     st[(size_t)ST_THETA0 * W.Bp + b] = -1.0, st[(size_t)ST_THMAX * W.Bp + b] = 0.0, st[(size_t)ST_THMIN * W.Bp + b] = 0.0;
     st[(size_t)ST_DW * W.Bp + b] = 0.0, st[(size_t)ST_DW_TRY * W.Bp + b] = 0.0;
     st[(size_t)ST_C00 * W.Bp + b] = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
+    st[(size_t)ST_RHO * W.Bp + b] = rho, st[(size_t)ST_VIOL * W.Bp + b] = 0.0;
     for (int i = 0; i < SI_NF; i++)
       if (i != SI_PREV) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;

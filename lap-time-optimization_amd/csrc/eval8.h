@@ -55,6 +55,7 @@ struct Lin8 {  // what lane (g, i) holds of its slot after lin8()
   double gv[3], gs[3], gn[3], gm[3];  // track constraints at x+ (same in all lanes)
   double rp_ineq, cmax, cmin, smult, th_ineq, sumlog;  // DUAL: per-lane partials over the inequalities this lane owns
   double csoft;                 // DUAL: penalty rho e of the soft track constraint this lane owns
+  double emax;                  // DUAL: its elastic variable
   double Yr[11], ABr[11];       // rows i of [Ac | Bc | bc] and [A | B | b]
   double Mir[8];                // EXPAND: row i of M8^-1
   int m_nl;
@@ -65,7 +66,7 @@ template <bool DUAL, bool EXPAND>
 __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, const int i, const int k, const int b,
                                      const double eps, Lin8& S) {
   const int N = W.N;
-  const double hdt = K.o.t_step, rho = K.o.soft_rho;
+  const double hdt = K.o.t_step, rho = W.st[(size_t)ST_RHO * W.Bp + b];
   const int pt = i >> 2;  // 0: this lane evaluates the model at c_k, 1: at x_{k+1}
   // ---- inputs
   double px[8], lam[8];
@@ -120,7 +121,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
   // ---- inequalities: the lane that owns component j adds the barrier terms of the bounds on it
   S.gc0 = 0.0, S.gc1 = 0.0, S.gx0 = S.gcost, S.gx1 = 0.0, S.dcd = 0.0, S.dxd = S.gcost;
   S.Du = 0.0, S.gub0 = 0.0, S.gub1 = 0.0, S.dud = 0.0;
-  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0, S.csoft = 0.0;
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0, S.csoft = 0.0, S.emax = 0.0;
   double hcd = 0.0, hxd = 0.0;  // additions to the diagonal entries Hc[i][i], Hx+[i][i]
   double lprod = 1.0;           // product of the slacks this lane owns (at most 6): one logarithm per lane
   S.m_nl = for_each_bound<BoundsAny>(K.p, [&](int m, int kind, int j, double sg, double val) {
@@ -170,7 +171,7 @@ __device__ __forceinline__ void lin8(const Consts& K, const Work& W, E8Lds& L, c
         if (rho > 0.0) {
           const double ez = e * (rho - nu);
           S.cmax = fmax(S.cmax, ez), S.cmin = fmin(S.cmin, ez), S.smult += fabs(rho - nu);
-          lprod *= e, S.csoft = rho * e;
+          lprod *= e, S.csoft = rho * e, S.emax = e;
         }
       }
     }
@@ -248,6 +249,12 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
   const int N = W.N;
   const double hdt = K.o.t_step;
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const bool reinit = W.si[(size_t)SI_REINIT * W.Bp + b] != 0;  // the restoration phase starts with this evaluation (see d_eval)
+  if (reinit) {
+    if (live && i == 0) reinit_slot<BoundsAny>(K, W, k, b);
+    WAVE_SYNC();
+    __threadfence();  // the other lanes of the slot read what lane 0 has just stored
+  }
   Lin8 S;
   lin8<true, false>(K, W, L, i, k, b, eps, S);
   // ---- residual partials (IPOPT's E_mu ingredients), see d_eval
@@ -260,7 +267,7 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
 #pragma unroll
     for (int a = 0; a < 8; a++) v[a] = S.E2r[a] * l2_i;
     double rxp = S.dxd - 0.5 * l1_i + tsum8(L, i, v);
-    if (k + 1 < N) rxp += 2.0 * PL(W.L1, i, k + 1, N) - 2.0 * PL(W.L2, i, k + 1, N);
+    if (k + 1 < N && !reinit) rxp += 2.0 * PL(W.L1, i, k + 1, N) - 2.0 * PL(W.L2, i, k + 1, N);
     double rd = fmax(fabs(rcx), fabs(rxp));
     double rp = fmax(fmax(fabs(S.G1), fabs(S.G2)), S.rp_ineq);
     double sm = fabs(l1_i) + fabs(l2_i) + S.smult;
@@ -278,10 +285,12 @@ __device__ __forceinline__ void d_eval8(const Consts& K, const Work& W, E8Lds& L
     const double cmax = grp_max(S.cmax), cmin = grp_min(S.cmin);
     const double cost = S.cost + grp_sum(cost_u + S.csoft);
     const double th0 = grp_sum(S.th_ineq + fabs(S.G1) + fabs(S.G2)), sumlog = grp_sum(S.sumlog);
+    const double emax = grp_max(S.emax);
     if (live && i == 0) {
       PL(W.LS, 0, k, N) = th0, PL(W.LS, 1, k, N) = cost, PL(W.LS, 2, k, N) = sumlog;
       PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
       PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
+      PL(W.RS, RS_emax, k, N) = emax;
     }
   }
   // ---- [A | B | b] (row i) and Hc Y (row i) from one pass over Y
@@ -368,7 +377,7 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
                                           const bool live) {
   const int N = W.N;
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
-  const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
+  const double tau = W.st[(size_t)ST_TAU * W.Bp + b], rho = W.st[(size_t)ST_RHO * W.Bp + b];
   Lin8 S;
   lin8<false, true>(K, W, L, i, k, b, eps, S);
   double dxk[8], dxp[8], du[2];
@@ -430,9 +439,9 @@ __device__ __forceinline__ void d_expand8(const Consts& K, const Work& W, E8Lds&
       const double gmq = i == 0 ? S.gm[0] : (i == 1 ? S.gm[1] : S.gm[2]);
       const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), it = 1.0 / t;
       const double gd = gsq * dxp[0] + gnq * dxp[1] + gmq * dxp[2];
-      if (K.o.soft_rho > 0.0) {
+      if (rho > 0.0) {
         double dtt, dn, dee;
-        track_soft_step(K.o.soft_rho, mu, tau, gvq, gd, t, nu, PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        track_soft_step(rho, mu, tau, gvq, gd, t, nu, PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
         if (live) PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
       } else {
         const double dtt = -(gvq + t) - gd;

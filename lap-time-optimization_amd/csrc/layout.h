@@ -35,7 +35,7 @@ enum : int {
 // fields of the Riccati buffer written by k_riccati and read by k_expand; stage index 0..N
 enum : int { RC_K = 0, RC_Kv = 16, RC_kff = 20, RC_P = 22, RC_Pxv = 58, RC_pp = 74, RC_NF = 82 };
 // residual partials written by k_eval (per k,b)
-enum : int { RS_rd = 0, RS_rp, RS_cmax, RS_cmin, RS_smult, RS_cost, RS_NF };
+enum : int { RS_rd = 0, RS_rp, RS_cmax, RS_cmin, RS_smult, RS_cost, RS_emax, RS_NF };  // RS_emax: largest elastic variable
 // step partials written by k_expand
 enum : int { SP_apri = 0, SP_adua, SP_gphid, SP_NF };
 // per-instance double state
@@ -43,14 +43,20 @@ enum : int {
   ST_MU = 0, ST_EPS, ST_EPS_NEXT, ST_DW_LAST, ST_FORCE_REG, ST_ALPHA, ST_ADUA, ST_E0, ST_OBJ, ST_TAU,
   ST_THETA0, ST_THMAX, ST_THMIN, ST_DW, ST_DW_TRY,
   ST_C00,  // lterm(x_0) for the current ST_EPS: a constant of the solve between two changes of the table smoothing
+  ST_RHO,  // penalty of the elastic variables of the track constraints: options.soft_rho, or options.resto_rho while
+           // the instance is in its restoration phase (0: hard constraints)
+  ST_VIOL, // largest elastic variable seen by the last termination test
   ST_NF
 };
 // per-instance int state
 // SI_LSMORE: the full step was rejected by the filter test, the remaining step candidates have to be evaluated.
 // SI_RETRY: the last Riccati sweep failed the inertia test; the next launch repeats it with ST_DW_TRY (no new
 // evaluation).  SI_SKIP_EVAL: the iterate did not move (failed line search), k_eval's output is still valid.
+// SI_RESTO: restoration phase (elastic mode): 0 not entered, 1 solving the elastic problem, 2 back on the
+// hard constraints.  SI_REINIT: set when the phase is entered; the next evaluation kernel first re-initialises the
+// slacks / multipliers of its slot from the primal point (the Riccati head clears the flag).
 enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
-             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
+             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_RESTO, SI_REINIT, SI_NRESTO, SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
 
 struct Work {
   int N, B, Bp;

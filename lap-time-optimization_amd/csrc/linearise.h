@@ -84,6 +84,52 @@ __device__ __forceinline__ void track_soft_step(const double rho, const double m
   gphid += rho * dee - mu * dtt * it - mu * dee * ie;
 }
 
+// Slacks, inequality multipliers (and elastic variables) of slot k from its primal point (k_init at the start of a
+// solve, reinit_slot when the restoration phase is entered): t = max(-h, bound_push), nu = mu / t.
+template <class BP>
+__device__ __forceinline__ void init_slot_slacks(const Consts& K, const Work& W, const int k, const int b, const double mu,
+                                                 const double eps, const double rho, const double* xp, const double* c,
+                                                 const double* u) {
+  const int N = W.N;
+  const int m = for_each_bound<BP>(K.p, [&](int mm, int kind, int j, double sg, double val) {
+    const double xv = kind == 0 ? u[j] : (kind == 1 ? c[j] : xp[j]);
+    const double hv = sg * (xv - val);
+    const double t = -hv > K.o.bound_push ? -hv : K.o.bound_push;
+    PL(W.T, mm, k, N) = t, PL(W.NU, mm, k, N) = mu / t;
+  });
+  double gv[3] = {-1.0, -1.0, -1.0};
+  if (k + 1 <= N - 1) cons_eval(K.p, K.T, eps, xp, gv, nullptr, nullptr, nullptr, nullptr, nullptr);
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    double t = -gv[q] > K.o.bound_push ? -gv[q] : K.o.bound_push, e = 0.0;
+    if (rho > 0.0) {
+      // softened: slack and multiplier as for the hard constraint (a violated constraint starts as an infeasibility of
+      // g - e + t = 0 that the Newton steps remove, not as a large elastic variable with nu ~ rho that the barrier lets
+      // go of only slowly); the elastic variable on the central path of its own pair, e (rho - nu) = mu.
+      // t >= 2 mu / rho keeps nu <= rho / 2.
+      t = fmax(t, 2.0 * mu / rho);
+      e = mu / (rho - mu / t);
+    }
+    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;
+  }
+}
+// Restoration entry (SI_REINIT, set by d_pick): the slot's slacks, multipliers and elastic variables start again from its
+// primal point with the instance's new barrier parameter and penalty, the collocation multipliers at zero.  Everything
+// written here belongs to slot k alone (the one neighbour's access, L1 / L2 of slot k + 1 in the dual residual of d_eval,
+// is replaced by zeros while the flag is set).
+template <class BP>
+__device__ __forceinline__ void reinit_slot(const Consts& K, const Work& W, const int k, const int b) {
+  const int N = W.N;
+  const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b], rho = W.st[(size_t)ST_RHO * W.Bp + b];
+  double xp[8], c[8], u[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) xp[i] = PL(W.X, i, k + 1, N + 1), c[i] = PL(W.C, i, k, N);
+  u[0] = PL(W.U, 0, k, N), u[1] = PL(W.U, 1, k, N);
+  init_slot_slacks<BP>(K, W, k, b, mu, eps, rho, xp, c, u);
+#pragma unroll
+  for (int i = 0; i < 8; i++) PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
+}
+
 // ------------------------------------------------------------------------------------------ slot linearisation
 // Slot k owns (u_k, c_k, x_{k+1}) and the collocation equations of interval k in do_mpc's Radau-IIA(2) form
 //   G1 = h f(c,u) + 2 x_k - 1.5 c - 0.5 x+ = 0 ,  G2 = h f(x+,u) - 2 x_k + 4.5 c - 2.5 x+ = 0   
@@ -99,6 +145,7 @@ struct Slot {
   double gv[3];                      // values of gL, gR+, gR- at x_{k+1}
   double rp_ineq, cmax, cmin, smult; // WITH_DUAL: max |h + t|, max / min t nu, sum |nu| over the slot's inequalities
   double th_ineq, sumlog;            // WITH_DUAL: sum |h + t|, sum log t (filter measures of the current point)
+  double emax;                       // WITH_DUAL: largest elastic variable of the slot (0 on hard constraints)
   double cost;
   int m_nl;                          // storage index of gL
   bool nl;
@@ -107,7 +154,7 @@ struct Slot {
 template <bool WITH_DUAL, class BP>
 __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
   const int N = W.N;
-  const double hdt = K.o.t_step, rho = K.o.soft_rho;
+  const double hdt = K.o.t_step, rho = W.st[(size_t)ST_RHO * W.Bp + b];
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     S.xk[i] = k == 0 ? W.x0[(size_t)i * W.Bp + b] : PL(W.X, i, k, N + 1);
@@ -144,7 +191,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   S.Du[0] = S.Du[1] = 0.0, S.gub0[0] = S.gub0[1] = 0.0, S.gub1[0] = S.gub1[1] = 0.0, S.dud[0] = S.dud[1] = 0.0;
   // inequalities: u bounds, c bounds, x+ bounds, nl constraints.  Barrier: Sigma = nu/t on the Hessian,
   // sigma = (mu + nu (h + t))/t = nu (h+t)/t + mu (1/t) on the gradient.
-  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0;
+  S.rp_ineq = 0.0, S.cmax = 0.0, S.cmin = 1e300, S.smult = 0.0, S.th_ineq = 0.0, S.sumlog = 0.0, S.emax = 0.0;
   double lprod = 1.0;  // sum of log t = log of products of 8 slacks (3 logarithms per slot, see d_linesearch)
   const int m_nl = for_each_bound<BP>(K.p, [&](int m, int kind, int j, double sg, double val) {
     const double xv = kind == 0 ? S.u[j] : (kind == 1 ? S.c[j] : S.xp[j]);
@@ -208,7 +255,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
         if (rho > 0.0) {
           const double ez = e * (rho - nu);
           S.cmax = fmax(S.cmax, ez), S.cmin = fmin(S.cmin, ez), S.smult += fabs(rho - nu);
-          lprod *= e, S.cost += rho * e;
+          lprod *= e, S.cost += rho * e, S.emax = fmax(S.emax, e);
         }
         if ((mm & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
       }
@@ -383,6 +430,8 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   if (!force && (W.si[(size_t)SI_RETRY * W.Bp + b] || W.si[(size_t)SI_SKIP_EVAL * W.Bp + b])) return;  // blocks of the last launch are still valid
   const double hdt = K.o.t_step;
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const bool reinit = W.si[(size_t)SI_REINIT * W.Bp + b] != 0;  // the restoration phase starts with this evaluation
+  if (reinit) reinit_slot<BP>(K, W, k, b);
   Slot S;
   linearise_slot<true, BP>(K, W, k, b, eps, S);
   // ---- node block of x_{k+1}: complete after the linearisation, stored now so that its 52 registers are free during
@@ -404,7 +453,7 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
 #pragma unroll
       for (int i = 0; i <= ge_(a); i++)  // column a of E1 / E2: rows of the groups up to a's
         if (a >= elo_(i) && a <= ehi_(i)) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
-      if (k + 1 < N) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);
+      if (k + 1 < N && !reinit) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);  // (re-initialised: zeros)
       rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
       rp = fmax(rp, fmax(fabs(S.G1[a]), fabs(S.G2[a])));
       sm += fabs(l1[a]) + fabs(l2[a]);
@@ -428,6 +477,7 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
     PL(W.LS, 0, k, N) = th0, PL(W.LS, 1, k, N) = cost, PL(W.LS, 2, k, N) = S.sumlog;
     PL(W.RS, RS_rd, k, N) = rd, PL(W.RS, RS_rp, k, N) = rp, PL(W.RS, RS_cmax, k, N) = cmax;
     PL(W.RS, RS_cmin, k, N) = cmin, PL(W.RS, RS_smult, k, N) = sm, PL(W.RS, RS_cost, k, N) = cost;
+    PL(W.RS, RS_emax, k, N) = S.emax;
   }
   // ---- eliminate the collocation point, project its QP block onto (x_k, u_k) ----
   M8Blocks M8;
@@ -489,7 +539,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double mu = W.st[(size_t)ST_MU * W.Bp + b], eps = W.st[(size_t)ST_EPS * W.Bp + b];
-  const double tau = W.st[(size_t)ST_TAU * W.Bp + b];
+  const double tau = W.st[(size_t)ST_TAU * W.Bp + b], rho = W.st[(size_t)ST_RHO * W.Bp + b];
   // costate pi_{k+1} = P_{k+1} dx_{k+1} + Pxv_{k+1} du_k + p_{k+1}: needs nothing of the linearisation, so it comes
   // first (its 60 words of the Riccati buffer are fetched in one batch while few registers are live; placed after the
   // elimination the compiler issued them one at a time, 40 serialised round trips).  Only pi is kept across the
@@ -593,7 +643,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         tt[m0 + q] = PL(W.T, m0 + q, k, N), nn[m0 + q] = PL(W.NU, m0 + q, k, N);
-        tt[m0 + 3 + q] = K.o.soft_rho > 0.0 ? PL(W.T, m0 + 3 + q, k, N) : 0.0;
+        tt[m0 + 3 + q] = rho > 0.0 ? PL(W.T, m0 + 3 + q, k, N) : 0.0;
       }
     }
   }
@@ -614,9 +664,9 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
     if (S.nl) {
       const double t = BP::fixed ? tt[m] : PL(W.T, m, k, N), nu = BP::fixed ? nn[m] : PL(W.NU, m, k, N), it = 1.0 / t;
       const double gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
-      if (K.o.soft_rho > 0.0) {
+      if (rho > 0.0) {
         double dtt, dn, dee;
-        track_soft_step(K.o.soft_rho, mu, tau, S.gv[q], gd, t, nu, BP::fixed ? tt[m + 3] : PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        track_soft_step(rho, mu, tau, S.gv[q], gd, t, nu, BP::fixed ? tt[m + 3] : PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
         PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
       } else {
         const double dtt = -(S.gv[q] + t) - gd;

@@ -18,7 +18,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   const int N = W.N;
   const double hdt = K.o.t_step;
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
-  const double eps = W.st[(size_t)ST_EPS * W.Bp + b];
+  const double eps = W.st[(size_t)ST_EPS * W.Bp + b], rho = W.st[(size_t)ST_RHO * W.Bp + b];
   double a_pri = 1.0;
   for (int kk = 0; kk < N; kk += 8) {  // eight loads in flight per round trip (a plain loop waits for every single one)
     double v8[8];
@@ -95,9 +95,9 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
         double t = PL(W.T, m + q, k, N) + alpha * PL(W.dT, m + q, k, N);
         double e = 0.0;
         pr *= t;
-        if (K.o.soft_rho > 0.0) {  // elastic variable of the softened constraint: g - e + t = 0, cost rho e
+        if (rho > 0.0) {  // elastic variable of the softened constraint: g - e + t = 0, cost rho e
           e = PL(W.T, m + 3 + q, k, N) + alpha * PL(W.dT, m + 3 + q, k, N);
-          pr *= e, co += K.o.soft_rho * e;
+          pr *= e, co += rho * e;
         }
         th += fabs(gv[q] - e + t);
         if (((m + q) & 7) == 7) sl += log(pr), pr = 1.0;
@@ -245,12 +245,17 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
   } else {
     STI(SI_LSMORE) = 0;
   }
-  bool take = true, give_up = false;
+  // Restoration phase (IPOPT enters its own when the filter line search fails): here an elastic mode, entered once per
+  // solve on the first failed search or after stall_iter tiny steps.
+  const bool resto_ready = o.resto_rho > 0.0 && !(o.soft_rho > 0.0) && STI(SI_RESTO) == 0;
+  bool take = true, give_up = false, enter_resto = false;
   if (!accepted) {
     const int nf = STI(SI_NLSFAIL) + 1;
     STI(SI_NLSFAIL) = nf;
     double fr = STD(ST_FORCE_REG);
-    if (o.max_ls_fail > 0 && nf >= o.max_ls_fail) {
+    if (resto_ready) {
+      enter_resto = true, take = false;
+    } else if (o.max_ls_fail > 0 && nf >= o.max_ls_fail) {
       give_up = true, take = false;
     } else if (fr < 1e4) {
       STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 : fr * 100.0;
@@ -266,9 +271,21 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
     int nt = alpha <= 1e-3 ? STI(SI_NTINY) + 1 : 0;
     STI(SI_NTINY) = nt;
     if (o.stall_iter > 0 && nt >= o.stall_iter) {
-      STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+      if (resto_ready) enter_resto = true;
+      else STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
       take = false;
     }
+  }
+  if (enter_resto) {
+    // the track constraints get elastic variables that cost resto_rho each; equality multipliers, slacks and the barrier
+    // parameter start again at the current primal point (the next evaluation kernel re-initialises its slots: SI_REINIT)
+    const double mu0 = o.mu_init;
+    STI(SI_RESTO) = 1, STI(SI_REINIT) = 1, STI(SI_NRESTO) += 1;
+    STD(ST_RHO) = o.resto_rho, STD(ST_MU) = mu0;
+    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu0) : 0.0;
+    if (STD(ST_EPS_NEXT) == STD(ST_EPS)) nfilt = 0, STD(ST_THETA0) = -1.0;  // (else: reset with the switch of the smoothing below)
+    STD(ST_DW_LAST) = 0.0, STD(ST_FORCE_REG) = 0.0;
+    STI(SI_NTINY) = 0, STI(SI_NACC) = 0;
   }
   STD(ST_ALPHA) = take ? alpha : 0.0, STD(ST_ADUA) = a_dua;
   STI(SI_STEP) = take ? 1 : 0;
@@ -287,7 +304,7 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
     eps_switched = true;
   }
   STI(SI_NFILT) = nfilt;
-  STI(SI_SKIP_EVAL) = (!take && !eps_switched) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
+  STI(SI_SKIP_EVAL) = (!take && !eps_switched && !enter_resto) ? 1 : 0;  // the iterate did not move: the stage blocks stay valid
 }
 
 __global__ void __launch_bounds__(64) k_pick(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase) {
@@ -322,7 +339,7 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
     double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
     PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
   }
-  if (K.o.soft_rho > 0.0 && nact == ni)
+  if (W.st[(size_t)ST_RHO * W.Bp + b] > 0.0 && nact == ni)
     for (int m = ni; m < ni + 3; m++) PL(W.T, m, k, N) += alpha * PL(W.dT, m, k, N);  // elastic variables
 }
 

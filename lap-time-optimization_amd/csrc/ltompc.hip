@@ -77,13 +77,17 @@ struct ltompc_solver {
   int last_launches = 0, last_iterations = 0;
 
   // (P may be a gptr<T>: a global-address-space pointer in the device pass of the compiler, a plain one on the host)
+  // work = true: an array that the kernels fill before they read it.  LTOMPC_POISON=1 (debug) fills those with 0xFF bytes
+  // (NaN as doubles) instead of zeros, so that a read of a never-written word shows up in the results
+  // (tests/test_gpu_parity.py::test_poisoned_work_buffers_give_identical_results).
+  bool poison = false;
   template <typename P>
-  int dalloc(P* p, size_t n) {
+  int dalloc(P* p, size_t n, bool work = false) {
     using T = std::remove_pointer_t<P>;
     void* q = nullptr;
     hipError_t e = hipMalloc(&q, n * sizeof(T));
     if (e != hipSuccess) return fail(std::string("hipMalloc: ") + hipGetErrorString(e));
-    e = hipMemsetAsync(q, 0, n * sizeof(T), stream);
+    e = hipMemsetAsync(q, (work && poison) ? 0xFF : 0, n * sizeof(T), stream);
     if (e != hipSuccess) return fail(std::string("hipMemset: ") + hipGetErrorString(e));
     allocs.push_back(q);
     *p = (P)q;
@@ -188,7 +192,7 @@ int ensure_unpacked(ltompc_solver* h) {
 extern "C" {
 
 const char* ltompc_last_error(void) { return g_err.c_str(); }
-const char* ltompc_version(void) { return "ltompc 0.4 (gfx950, fp64; block-structured interval evaluation, LDS-staged wave-cooperative Riccati, data re-packing)"; }
+const char* ltompc_version(void) { return "ltompc 0.5 (gfx950, fp64; interior point with elastic-mode restoration, block-structured interval evaluation, LDS-staged wave-cooperative Riccati, data re-packing)"; }
 
 void ltompc_default_params(ltompc_params* p) {
   std::memset(p, 0, sizeof *p);
@@ -218,6 +222,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1;
+  o->resto_rho = 1000.0, o->max_soc = 0;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
@@ -229,6 +234,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (options->n_linesearch < 1 || options->n_linesearch > MAX_LS) return fail("ltompc_create: n_linesearch out of range");
   if (!(options->t_step > 0)) return fail("ltompc_create: t_step must be positive");
   if (!(options->soft_rho >= 0) || !std::isfinite(options->soft_rho)) return fail("ltompc_create: soft_rho must be >= 0 (0 = hard track constraints)");
+  if (!(options->resto_rho >= 0) || !std::isfinite(options->resto_rho)) return fail("ltompc_create: resto_rho must be >= 0 (0 = no restoration phase)");
+  if (options->max_soc != 0) return fail("ltompc_create: max_soc must be 0 (the second-order correction exists in the oracle only, see include/ltompc.h)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
     for (int i = 0; i < n_table; i++)
       if (!std::isfinite(tables[(size_t)r * n_table + i])) return fail("ltompc_create: non-finite table entry");
@@ -252,6 +259,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   {
     const char* e = getenv("LTOMPC_RICCATI");
     h->serial_riccati = e && std::string(e) == "serial";
+    const char* po = getenv("LTOMPC_POISON");
+    h->poison = po && std::string(po) == "1";
     const char* c = getenv("LTOMPC_COMPACT");
     h->compaction = !(c && std::string(c) == "0");
     const char* pk = getenv("LTOMPC_PACK");
@@ -296,16 +305,16 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   W.N = h->N, W.B = h->B, W.Bp = h->Bp;
   int rc = 0;
   rc |= h->dalloc(&h->d_tables, (size_t)LTOMPC_TABLE_ROWS * n_table);
-  rc |= h->dalloc(&W.X, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.C, 8 * N * Bp), rc |= h->dalloc(&W.U, 2 * N * Bp);
-  rc |= h->dalloc(&W.L1, 8 * N * Bp), rc |= h->dalloc(&W.L2, 8 * N * Bp);
-  rc |= h->dalloc(&W.T, (ni + NNL) * N * Bp), rc |= h->dalloc(&W.NU, ni * N * Bp);  // T: slacks + elastic variables (soft_rho)
-  rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp), rc |= h->dalloc(&W.dC, 8 * N * Bp), rc |= h->dalloc(&W.dU, 2 * N * Bp);
-  rc |= h->dalloc(&W.nL1, 8 * N * Bp), rc |= h->dalloc(&W.nL2, 8 * N * Bp);
-  rc |= h->dalloc(&W.dT, (ni + NNL) * N * Bp), rc |= h->dalloc(&W.dNU, ni * N * Bp);
-  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp + 64), rc |=  // (+64: k_riccati8 fetches one field past the last block)
-  h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp);
-  rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp);
-  rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp);
+  rc |= h->dalloc(&W.X, 8 * (N + 1) * Bp, true), rc |= h->dalloc(&W.C, 8 * N * Bp, true), rc |= h->dalloc(&W.U, 2 * N * Bp, true);
+  rc |= h->dalloc(&W.L1, 8 * N * Bp, true), rc |= h->dalloc(&W.L2, 8 * N * Bp, true);
+  rc |= h->dalloc(&W.T, (ni + NNL) * N * Bp, true), rc |= h->dalloc(&W.NU, ni * N * Bp, true);  // T: slacks + elastic variables
+  rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp, true), rc |= h->dalloc(&W.dC, 8 * N * Bp, true), rc |= h->dalloc(&W.dU, 2 * N * Bp, true);
+  rc |= h->dalloc(&W.nL1, 8 * N * Bp, true), rc |= h->dalloc(&W.nL2, 8 * N * Bp, true);
+  rc |= h->dalloc(&W.dT, (ni + NNL) * N * Bp, true), rc |= h->dalloc(&W.dNU, ni * N * Bp, true);
+  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp + 64, true), rc |=  // (+64: k_riccati8 fetches one field past the last block)
+  h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp, true);
+  rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp, true), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp, true);
+  rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp, true);
   rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);
   rc |= h->dalloc(&W.st, (size_t)ST_NF * Bp), rc |= h->dalloc(&W.filt, (size_t)2 * FILTER_MAX * Bp);
   rc |= h->dalloc(&W.si, (size_t)SI_NF * Bp), rc |= h->dalloc(&W.active, (size_t)h->max_iter + 2);
@@ -545,6 +554,23 @@ int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail) {
   for (int b = 0; b < h->B; b++) {
     if (n_reg) n_reg[b] = si[(size_t)SI_NREG * h->Bp + b];
     if (n_lsfail) n_lsfail[b] = si[(size_t)SI_NLSFAIL * h->Bp + b];
+  }
+  return 0;
+}
+
+int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
+  std::vector<int> si((size_t)SI_NF * h->Bp);
+  std::vector<double> st((size_t)ST_NF * h->Bp);
+  HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(st.data(), h->W.st, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++) {
+    if (n_resto) n_resto[b] = si[(size_t)SI_NRESTO * h->Bp + b];
+    // (meaningful while the elastic variables exist: 0 once the solve is back on the hard constraints)
+    if (violation) violation[b] = st[(size_t)ST_RHO * h->Bp + b] > 0.0 ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
   }
   return 0;
 }

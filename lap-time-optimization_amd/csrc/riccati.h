@@ -20,21 +20,23 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   if (STI(SI_DONE)) return;
   const ltompc_options& o = K.o;
   // ---- reduce residual partials, KKT error, termination (IPOPT eq. (5),(6)) ----
-  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, smult = 0.0;
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, smult = 0.0, emax = 0.0;
   double obj;
   obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
   for (int k = 0; k < N; k++) {
     rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
     cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
     smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
+    emax = fmax(emax, PL(W.RS, RS_emax, k, N));
   }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (last slot has no nl constraints)
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (STD(ST_RHO) > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (last slot has no nl constraints)
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
   double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
   double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  STD(ST_E0) = E0, STD(ST_OBJ) = obj;
+  STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = emax;
+  STI(SI_REINIT) = 0;
   int iters = STI(SI_ITERS);
   int term = -1;
   if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
@@ -46,6 +48,17 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
       if (na >= o.acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE;
     } else STI(SI_NACC) = 0;
     if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+  }
+  if (STI(SI_RESTO) == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {  // see d_head8
+    const double e_tol = term == LTOMPC_STATUS_SOLVED ? o.tol : o.acceptable_tol;
+    if (emax <= e_tol) {
+      STI(SI_RESTO) = 2, STD(ST_RHO) = 0.0;
+      STI(SI_NACC) = 0, STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+      STI(SI_STEP) = 0, STI(SI_SKIP_EVAL) = 0;
+      atomicAdd(&W.active[it_index], 1);
+      return;
+    }
+    term = LTOMPC_STATUS_INFEASIBLE;
   }
   if (term >= 0) {
     STI(SI_STATUS) = term, STI(SI_DONE) = 1;
@@ -267,6 +280,108 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   STI(SI_STEP) = 1;
 }
 
+// ------------------------------------------------------------------------------------------ head of an iteration
+// KKT error, termination test, restoration bookkeeping and the monotone barrier update of one instance, by the 8 lanes
+// (lane = g + 8 i) that own it in d_riccati8 / d_riccati1: lane i reduces the partials of the intervals k = i, i + 8, ...;
+// the sums over k are formed in the order k = 0..N-1 by every lane (identical to the serial kernel, so that all three
+// produce the same bits).  Returns false when no lane of the wavefront has a sweep to do.
+__device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const int i, const int b, const bool valid,
+                                        const int active_slot, bool& live, bool& retry, double& mu) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  const ltompc_options& o = K.o;
+  live = valid && !STI(SI_DONE);
+  retry = false;
+  mu = 0.0;
+  if (!__any(live)) return false;
+  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
+  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
+  // than one sweep however hard the worst instance of the batch is.
+  retry = live && STI(SI_RETRY);
+  const double rho = STD(ST_RHO);
+  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, emax = 0.0;
+  for (int k = i; k < N; k += 8) {
+    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
+    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
+    emax = fmax(emax, PL(W.RS, RS_emax, k, N));
+  }
+  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin), emax = grp_max(emax);
+  double smult = 0.0, obj;
+  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
+  for (int k0 = 0; k0 < N; k0 += 8) {  // same order of additions as the serial kernel, eight loads in flight per round trip
+    double sm8[8], co8[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int k = k0 + q < N ? k0 + q : N - 1;
+      sm8[q] = PL(W.RS, RS_smult, k, N), co8[q] = PL(W.RS, RS_cost, k, N);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (k0 + q < N) smult += sm8[q], obj += co8[q];
+  }
+  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (rho > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (the last slot has no track constraints)
+  mu = STD(ST_MU);
+  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  int term = -1;
+  bool to_hard = false;
+  if (live && !retry) {
+    int iters = STI(SI_ITERS);
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
+      if (i == 0) STI(SI_NACC) = na;
+      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (STI(SI_RESTO) == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {
+      // The elastic problem of the restoration phase has converged.  All elastic variables at (numerically) zero: its
+      // solution is a KKT point of the hard-constrained NLP with the same multipliers (nu < rho): back to the hard
+      // constraints, where the termination test is repeated on the hard problem's own KKT error (this launch does no
+      // sweep for the instance; the pass is not counted as an iteration).  Otherwise the violation cannot be removed
+      // locally: a stationary point of the infeasibility.
+      const double e_tol = term == LTOMPC_STATUS_SOLVED ? o.tol : o.acceptable_tol;
+      if (emax <= e_tol) to_hard = true, term = -1;
+      else term = LTOMPC_STATUS_INFEASIBLE;
+    }
+    if (i == 0) {
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = emax;
+      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
+      if (to_hard) {
+        STI(SI_RESTO) = 2, STD(ST_RHO) = 0.0;
+        STI(SI_NACC) = 0, STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+        STI(SI_STEP) = 0, STI(SI_SKIP_EVAL) = 0;
+      }
+    }
+    if (term >= 0) live = false;
+  }
+  if (valid && i == 0 && STI(SI_REINIT)) STI(SI_REINIT) = 0;  // the evaluation before this head has re-initialised the slots
+  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
+  if (to_hard) live = false;  // (counted as unfinished above)
+  if (!__any(live)) return false;
+  // ---- monotone barrier update
+  bool mu_changed = false;
+  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
+    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
+    mu_changed = true;
+    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  }
+  if (live && !retry && i == 0) {
+    if (mu_changed) {
+      STD(ST_MU) = mu;
+      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+    }
+    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  }
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------ k_riccati8
 // Wave-cooperative form of k_riccati: a wavefront = 8 instances x 8 lanes, lane (g, i) = (lane & 7, lane >> 3)
 // owns ROW i of the 8x8 blocks of instance b = 8 * blockIdx.x + g.  With the instance index fastest in HBM the
@@ -296,74 +411,9 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   double* st = W.st;
   int* si = W.si;
   const ltompc_options& o = K.o;
-  bool live = valid && !STI(SI_DONE);
-  if (!__any(live)) return;
-  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
-  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
-  // than one sweep however hard the worst instance of the batch is.
-  const bool retry = live && STI(SI_RETRY);
-  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
-  //      every lane (identical to the serial kernel, so that both produce the same bits)
-  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
-  for (int k = i; k < N; k += 8) {
-    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
-    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
-  }
-  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
-  double smult = 0.0, obj;
-  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
-  for (int k0 = 0; k0 < N; k0 += 8) {  // same order of additions as the serial kernel, eight loads in flight per round trip
-    double sm8[8], co8[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int k = k0 + q < N ? k0 + q : N - 1;
-      sm8[q] = PL(W.RS, RS_smult, k, N), co8[q] = PL(W.RS, RS_cost, k, N);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      if (k0 + q < N) smult += sm8[q], obj += co8[q];
-  }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
-  double mu = STD(ST_MU);
-  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
-  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
-  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  int term = -1;
-  if (live && !retry) {
-    int iters = STI(SI_ITERS);
-    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
-    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
-    else {
-      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
-      if (i == 0) STI(SI_NACC) = na;
-      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
-      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
-    }
-    if (i == 0) {
-      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
-      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
-    }
-    if (term >= 0) live = false;
-  }
-  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
-  if (!__any(live)) return;
-  // ---- monotone barrier update
-  bool mu_changed = false;
-  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
-    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-    mu_changed = true;
-    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  }
-  if (live && !retry && i == 0) {
-    if (mu_changed) {
-      STD(ST_MU) = mu;
-      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
-      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
-    }
-    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
-  }
+  bool live, retry;
+  double mu;
+  if (!d_head8(K, W, i, b, valid, active_slot, live, retry, mu)) return;
   // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
   //      the others recompute the same numbers)
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
@@ -683,74 +733,9 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
   long long rt0 = rprof ? clock64() : 0;
 #define RTOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
-  bool live = valid && !STI(SI_DONE);
-  if (!__any(live)) return;
-  // One sweep per launch: an instance whose sweep fails the inertia test repeats it in the NEXT launch with a larger
-  // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
-  // than one sweep however hard the worst instance of the batch is.
-  const bool retry = live && STI(SI_RETRY);
-  // ---- residual partials: lane i reduces k = i, i+8, ...; the sum over k is done in the order k = 0..N-1 by
-  //      every lane (identical to the serial kernel, so that both produce the same bits)
-  double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300;
-  for (int k = i; k < N; k += 8) {
-    rd = fmax(rd, PL(W.RS, RS_rd, k, N)), rp = fmax(rp, PL(W.RS, RS_rp, k, N));
-    cmax = fmax(cmax, PL(W.RS, RS_cmax, k, N)), cmin = fmin(cmin, PL(W.RS, RS_cmin, k, N));
-  }
-  rd = grp_max(rd), rp = grp_max(rp), cmax = grp_max(cmax), cmin = grp_min(cmin);
-  double smult = 0.0, obj;
-  obj = STD(ST_C00);  // lterm(x_0), kept by k_init / d_pick
-  for (int k0 = 0; k0 < N; k0 += 8) {  // same order of additions as the serial kernel, eight loads in flight per round trip
-    double sm8[8], co8[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int k = k0 + q < N ? k0 + q : N - 1;
-      sm8[q] = PL(W.RS, RS_smult, k, N), co8[q] = PL(W.RS, RS_cost, k, N);
-    }
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      if (k0 + q < N) smult += sm8[q], obj += co8[q];
-  }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (K.o.soft_rho > 0.0 ? 3 * (N - 1) : 0);
-  double mu = STD(ST_MU);
-  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
-  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
-  double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  int term = -1;
-  if (live && !retry) {
-    int iters = STI(SI_ITERS);
-    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
-    else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
-    else {
-      int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
-      if (i == 0) STI(SI_NACC) = na;
-      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
-      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
-    }
-    if (i == 0) {
-      STD(ST_E0) = E0, STD(ST_OBJ) = obj;
-      if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
-    }
-    if (term >= 0) live = false;
-  }
-  if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
-  if (!__any(live)) return;
-  // ---- monotone barrier update
-  bool mu_changed = false;
-  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
-    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-    mu_changed = true;
-    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  }
-  if (live && !retry && i == 0) {
-    if (mu_changed) {
-      STD(ST_MU) = mu;
-      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
-      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
-    }
-    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
-  }
+  bool live, retry;
+  double mu;
+  if (!d_head8(K, W, i, b, valid, active_slot, live, retry, mu)) return;
   // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
   //      the others recompute the same numbers)
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};

@@ -88,7 +88,9 @@ class BatchedMPC:
         check(lib().ltompc_get_stats(self._h, iptr(st), iptr(it), dptr(kkt), dptr(obj), dptr(mu)))
         nr, nf = np.empty(self.B, dtype=np.int32), np.empty(self.B, dtype=np.int32)
         check(lib().ltompc_get_counters(self._h, iptr(nr), iptr(nf)))
-        return dict(status=st, iters=it, kkt=kkt, obj=obj, mu=mu, n_reg=nr, n_lsfail=nf)
+        nre, viol = np.empty(self.B, dtype=np.int32), np.empty(self.B)
+        check(lib().ltompc_get_restoration(self._h, iptr(nre), dptr(viol)))
+        return dict(status=st, iters=it, kkt=kkt, obj=obj, mu=mu, n_reg=nr, n_lsfail=nf, n_resto=nre, viol=viol)
 
     def plant_step(self, x, u, n_sub: int = 400):
         x, u = self._x(x), np.ascontiguousarray(np.asarray(u, float).reshape(self.B, NU))

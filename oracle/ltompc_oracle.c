@@ -456,9 +456,11 @@ static void slot_ineq(const ltompc_params* p, const tables_t* T, const bounds_t*
   for (int q = 0; q < NNL; q++) h[m] = g[q] - (e && nl ? e[q] : 0.0), active[m++] = nl; /* soft: h = g - e */
 }
 
-/* filter-line-search measures at a (trial) point: theta = ||c||_1 + ||h + t||_1, cost, sum ln t */
-static void eval_measures(const ltompc_params* p, const ltompc_options* o, const tables_t* T, const bounds_t* bd,
-                          const iterate_t* it, const double* uprev, double* theta, double* cost, double* sumlog) {
+/* constraint residuals of an iterate: collocation equations G1, G2 (N x 8 each) and inequality rows r = h + t
+ * (N x MAXI; soft track constraints: h = g - e); also the filter measures theta = ||.||_1, cost, sum of logs. */
+static void eval_residuals(const ltompc_params* p, const ltompc_options* o, const tables_t* T, const bounds_t* bd,
+                           const iterate_t* it, const double* uprev, double* G1, double* G2, double* R, double* theta,
+                           double* cost, double* sumlog) {
   int N = it->N;
   double th = 0, co = 0, sl = 0, hdt = o->t_step;
   co += cost_val(p, T, it->x, 0); /* lterm(x_0): constant, kept so that J matches the NLP objective */
@@ -469,24 +471,30 @@ static void eval_measures(const ltompc_params* p, const ltompc_options* o, const
     rhs_val(p, T, c, u, f1);
     rhs_val(p, T, xp, u, f2);
     for (int i = 0; i < NX; i++) {
-      th += fabs(hdt * f1[i] + 2 * xk[i] - 1.5 * c[i] - 0.5 * xp[i]);
-      th += fabs(hdt * f2[i] - 2 * xk[i] + 4.5 * c[i] - 2.5 * xp[i]);
+      double a = hdt * f1[i] + 2 * xk[i] - 1.5 * c[i] - 0.5 * xp[i];
+      double b = hdt * f2[i] - 2 * xk[i] + 4.5 * c[i] - 2.5 * xp[i];
+      th += fabs(a);
+      th += fabs(b);
+      if (G1) G1[k * NX + i] = a, G2[k * NX + i] = b;
     }
     co += cost_val(p, T, xp, k == N - 1);
     for (int i = 0; i < NU; i++) co += p->r_du[i] * (u[i] - v[i]) * (u[i] - v[i]);
     double h[MAXI];
     int act[MAXI];
     slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, h, act);
-    for (int m = 0; m < bd->ni; m++)
+    for (int m = 0; m < bd->ni; m++) {
+      if (R) R[k * MAXI + m] = 0.0;
       if (act[m]) {
         double t = it->t[k * MAXI + m];
         th += fabs(h[m] + t);
+        if (R) R[k * MAXI + m] = h[m] + t;
         sl += log(t);
         if (it->rho > 0 && m >= bd->ni - NNL) {
           double e = it->e[k * NNL + m - (bd->ni - NNL)];
           sl += log(e), co += it->rho * e;
         }
       }
+    }
   }
   *theta = th, *cost = co, *sumlog = sl;
 }
@@ -503,7 +511,37 @@ typedef struct {
   double h[MAXI];
   int act[MAXI];
   double cost;
+  /* right-hand side of the Newton system: the constraint residuals the step has to remove.  At the iterate they are
+   * G1, G2, h + t; a second-order correction replaces them by alpha c(x) + c(x + alpha d) (same matrix). */
+  double rG1[8], rG2[8], rI[MAXI];
 } slot_lin;
+
+/* Gradient blocks of the stage QP for the current right-hand-side residuals (L->rI) and barrier parameter.
+ * Barrier: sigma = (mu + nu r) / t per inequality with residual r = h + t.  Softened track constraint (rho > 0):
+ * g - e + t = 0, e >= 0 with multiplier z = rho - nu; eliminating (dt, de, dnu) gives
+ * dnu = Sg (grad g . dx + geff + mu / nu - mu / z), geff = r + e - t (= g at the iterate). */
+static void slot_gradients(const bounds_t* bd, const iterate_t* it, int k, double mu, slot_lin* L) {
+  const double *t = it->t + k * MAXI, *nu = it->nu + k * MAXI;
+  for (int a = 0; a < NX; a++) L->gc[a] = 0.0, L->gxp[a] = L->gcost[a];
+  L->gub[0] = L->gub[1] = 0.0;
+  int m = 0;
+  for (int i = 0; i < bd->n_ub; i++, m++) L->gub[bd->ub_idx[i]] += bd->ub_sgn[i] * ((mu + nu[m] * L->rI[m]) / t[m]);
+  for (int i = 0; i < bd->n_xb; i++, m++) L->gc[bd->xb_idx[i]] += bd->xb_sgn[i] * ((mu + nu[m] * L->rI[m]) / t[m]);
+  for (int i = 0; i < bd->n_xb; i++, m++) L->gxp[bd->xb_idx[i]] += bd->xb_sgn[i] * ((mu + nu[m] * L->rI[m]) / t[m]);
+  if (L->act[m])
+    for (int q = 0; q < NNL; q++) {
+      int mm = m + q;
+      double sg = (mu + nu[mm] * L->rI[mm]) / t[mm];
+      if (it->rho > 0) {
+        double e = it->e[k * NNL + q], z = it->rho - nu[mm];
+        double Sg = 1.0 / (t[mm] / nu[mm] + e / z);
+        /* (geff from the SAME numbers the step recovery uses: a difference of one ulp of the O(1) terms of g is
+         *  amplified by Sg ~ nu / t ~ 1e9 into the dual residual) */
+        sg = (nu[mm] + Sg * (L->rI[mm] + e - t[mm])) + mu * (Sg * (1.0 / nu[mm] - 1.0 / z));
+      }
+      for (int a = 0; a < NX; a++) L->gxp[a] += sg * L->gnl[q][a];
+    }
+}
 
 static void linearise_slot(const ltompc_params* p, const ltompc_options* o, const tables_t* T, const bounds_t* bd,
                            const iterate_t* it, int k, double mu, slot_lin* L) {
@@ -524,6 +562,7 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
     double f1 = i < 6 ? F1.f[i].v : u[i - 6], f2 = i < 6 ? F2.f[i].v : u[i - 6];
     L->G1[i] = hdt * f1 + 2 * xk[i] - 1.5 * c[i] - 0.5 * xp[i];
     L->G2[i] = hdt * f2 - 2 * xk[i] + 4.5 * c[i] - 2.5 * xp[i];
+    L->rG1[i] = L->G1[i], L->rG2[i] = L->G2[i];
   }
   for (int i = 0; i < 6; i++)
     for (int a = 0; a < NX; a++)
@@ -535,29 +574,26 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
   L->cost = cj.v;
   for (int a = 0; a < NX; a++) {
     L->gcost[a] = cj.g[a];
-    L->gxp[a] = cj.g[a];
     L->dxp_dual[a] = cj.g[a];
-    L->gc[a] = 0, L->dc_dual[a] = 0;
+    L->dc_dual[a] = 0;
     for (int b = 0; b < NX; b++) L->Hxp[a * 8 + b] += cj.h[hidx(a, b)];
   }
-  L->Du[0] = L->Du[1] = 0, L->gub[0] = L->gub[1] = 0, L->du_dual[0] = L->du_dual[1] = 0;
+  L->Du[0] = L->Du[1] = 0, L->du_dual[0] = L->du_dual[1] = 0;
   slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, L->h, L->act);
-  /* barrier contributions: Sigma = nu/t on the Hessian, sigma = (mu + nu (h + t))/t on the gradient */
+  for (int m = 0; m < bd->ni; m++) L->rI[m] = L->act[m] ? L->h[m] + t[m] : 0.0;
+  /* barrier contributions to the Hessian: Sigma = nu/t */
   int m = 0;
   for (int i = 0; i < bd->n_ub; i++, m++) {
-    double Sg = nu[m] / t[m], sg = (mu + nu[m] * (L->h[m] + t[m])) / t[m];
     int j = bd->ub_idx[i];
-    L->Du[j] += Sg, L->gub[j] += bd->ub_sgn[i] * sg, L->du_dual[j] += bd->ub_sgn[i] * nu[m];
+    L->Du[j] += nu[m] / t[m], L->du_dual[j] += bd->ub_sgn[i] * nu[m];
   }
   for (int i = 0; i < bd->n_xb; i++, m++) {
-    double Sg = nu[m] / t[m], sg = (mu + nu[m] * (L->h[m] + t[m])) / t[m];
     int j = bd->xb_idx[i];
-    L->Hc[j * 8 + j] += Sg, L->gc[j] += bd->xb_sgn[i] * sg, L->dc_dual[j] += bd->xb_sgn[i] * nu[m];
+    L->Hc[j * 8 + j] += nu[m] / t[m], L->dc_dual[j] += bd->xb_sgn[i] * nu[m];
   }
   for (int i = 0; i < bd->n_xb; i++, m++) {
-    double Sg = nu[m] / t[m], sg = (mu + nu[m] * (L->h[m] + t[m])) / t[m];
     int j = bd->xb_idx[i];
-    L->Hxp[j * 8 + j] += Sg, L->gxp[j] += bd->xb_sgn[i] * sg, L->dxp_dual[j] += bd->xb_sgn[i] * nu[m];
+    L->Hxp[j * 8 + j] += nu[m] / t[m], L->dxp_dual[j] += bd->xb_sgn[i] * nu[m];
   }
   memset(L->gnl, 0, sizeof L->gnl);
   if (L->act[m]) {
@@ -565,22 +601,19 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
     cons_jet(p, T, xp, g);
     for (int q = 0; q < NNL; q++) {
       int mm = m + q;
-      double Sg = nu[mm] / t[mm], sg = (mu + nu[mm] * (L->h[mm] + t[mm])) / t[mm];
+      double Sg = nu[mm] / t[mm];
       if (it->rho > 0) { /* softened: g - e + t = 0, e >= 0 with multiplier z = rho - nu */
         double e = it->e[k * NNL + q], z = it->rho - nu[mm];
         Sg = 1.0 / (t[mm] / nu[mm] + e / z);
-        /* (the constraint value h + e of slot_ineq, not the jet's: the step recovery below must see the SAME number,
-         *  a difference of one ulp of the O(1) terms of g is amplified by Sg ~ nu / t ~ 1e9 into the dual residual) */
-        sg = (nu[mm] + Sg * (L->h[mm] + e)) + mu * (Sg * (1.0 / nu[mm] - 1.0 / z));
       }
       for (int a = 0; a < NX; a++) {
         L->gnl[q][a] = g[q].g[a];
-        L->gxp[a] += sg * g[q].g[a];
         L->dxp_dual[a] += nu[mm] * g[q].g[a];
         for (int b = 0; b < NX; b++) L->Hxp[a * 8 + b] += nu[mm] * g[q].h[hidx(a, b)] + Sg * g[q].g[a] * g[q].g[b];
       }
     }
   }
+  slot_gradients(bd, it, k, mu, L);
 }
 
 /* ------------------------------------------------------------------ the interior-point solve */
@@ -591,71 +624,354 @@ typedef struct {
   double Q[64], S[16], R[4], q[8], r[2]; /* condensed-c + u-barrier contributions in (x_k,u_k) */
   double K[16], Kv[4], kff[2];           /* du = kff + K dx + Kv dv */
   double P[64], Pxv[16], Pvv[4], pp[8], pv[2];
+  double Hux[16], Hi[4];                 /* kept for right-hand-side-only sweeps (second-order correction) */
 } stage_ws;
 
 typedef struct {
   int status, iters;
   double kkt, obj, mu;
-  int n_reg, n_lsfail;
+  int n_reg, n_lsfail, n_soc, n_resto;
+  double viol; /* largest elastic variable at termination (0 on the hard constraints) */
 } solve_stats;
 
 #define FILTER_MAX 64
 #define DW_KEEP 1e-5
 
-static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
-                     const double* uprev, int warm, double* X, double* C, double* U, double* L1, double* L2,
-                     double* Tout, double* NUout, solve_stats* st) {
+/* everything one solve works on */
+typedef struct {
+  const ltompc_params* p;
+  const ltompc_options* o;
+  tables_t* T;
   bounds_t bd;
-  build_bounds(p, &bd);
-  const int ni = bd.ni;
-  const double hdt = o->t_step;
-  tables_t Tl = *T0;
-  tables_t* T = &Tl;
-#define SET_SMOOTHING(mu_) \
-  (Tl.eps_mu = 0.0, Tl.eps_s = (o->smooth_scale > 0 || o->smooth_eps_min > 0) ? fmax(o->smooth_eps_min, o->smooth_scale * (mu_)) : 0.0)
-  SET_SMOOTHING(o->mu_init);
-  iterate_t it = it_alloc(N), tr = it_alloc(N);
-  const double rho = o->soft_rho;
-  it.rho = tr.rho = rho;
-  double* de = calloc((size_t)N * NNL, sizeof(double));
-  slot_lin* L = malloc(sizeof(slot_lin) * (size_t)N);
-  stage_ws* W = malloc(sizeof(stage_ws) * (size_t)N);
-  double* dx = calloc((size_t)(N + 1) * NX, sizeof(double));
-  double* dc = calloc((size_t)N * NX, sizeof(double));
-  double* du = calloc((size_t)N * NU, sizeof(double));
-  double* nl1 = calloc((size_t)N * NX, sizeof(double));
-  double* nl2 = calloc((size_t)N * NX, sizeof(double));
-  double* dt = calloc((size_t)N * MAXI, sizeof(double));
-  double* dnu = calloc((size_t)N * MAXI, sizeof(double));
+  int N, ni;
+  double hdt;
+  const double* uprev;
+  iterate_t it, tr;
+  slot_lin* L;
+  stage_ws* W;
+  double *dx, *dc, *du, *nl1, *nl2, *dt, *dnu, *de;
+  double mu, delta_w;
+} ipws;
 
-  /* ---- initial point: do_mpc set_initial_guess (all slots = x0, u = 0) or the previous solution ---- */
-  if (!warm) {
-    for (int k = 0; k <= N; k++) memcpy(it.x + k * NX, x0, sizeof(double) * NX);
-    for (int k = 0; k < N; k++) memcpy(it.c + k * NX, x0, sizeof(double) * NX);
-  } else {
-    memcpy(it.x, X, sizeof(double) * (size_t)(N + 1) * NX);
-    memcpy(it.c, C, sizeof(double) * (size_t)N * NX);
-    memcpy(it.u, U, sizeof(double) * (size_t)N * NU);
-    memcpy(it.l1, L1, sizeof(double) * (size_t)N * NX);
-    memcpy(it.l2, L2, sizeof(double) * (size_t)N * NX);
-    if (o->warm_shift) { /* option: shift the previous solution by one interval (last interval repeated) */
-      for (int k = 0; k + 1 < N; k++) {
-        memcpy(it.x + k * NX, X + (k + 1) * NX, sizeof(double) * NX);
-        memcpy(it.c + k * NX, C + (k + 1) * NX, sizeof(double) * NX);
-        memcpy(it.u + k * NU, U + (k + 1) * NU, sizeof(double) * NU);
-        memcpy(it.l1 + k * NX, L1 + (k + 1) * NX, sizeof(double) * NX);
-        memcpy(it.l2 + k * NX, L2 + (k + 1) * NX, sizeof(double) * NX);
-      }
-      memcpy(it.x + (N - 1) * NX, X + N * NX, sizeof(double) * NX);
+/* matrix part of the elimination of the collocation point: [dc; dx+] = M^-1 (-[G1;G2] - [2;-2] dx - [Bu;Bu] du),
+ * and the projection of the c-block of the QP onto (x_k, u_k) */
+static int condense_matrices(ipws* s, int k) {
+  stage_ws* w = &s->W[k];
+  slot_lin* L = s->L;
+  double* M = w->M;
+  memset(M, 0, sizeof w->M);
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) {
+      M[i * 16 + j] = L[k].E1[i * 8 + j];
+      M[(8 + i) * 16 + 8 + j] = L[k].E2[i * 8 + j];
     }
-    memcpy(it.x, x0, sizeof(double) * NX); /* node 0 is the measured state */
+  for (int i = 0; i < 8; i++) M[i * 16 + 8 + i] = -0.5, M[(8 + i) * 16 + i] = 4.5;
+  if (lu_factor(M, 16, w->piv)) return -1;
+  for (int col = 0; col < 10; col++) {
+    double rhs[16];
+    for (int i = 0; i < 8; i++) {
+      if (col < 8) rhs[i] = (i == col) ? -2.0 : 0.0, rhs[8 + i] = (i == col) ? 2.0 : 0.0;
+      else rhs[i] = rhs[8 + i] = (i == 6 + (col - 8)) ? -s->hdt : 0.0;
+    }
+    lu_solve(M, 16, w->piv, rhs);
+    for (int i = 0; i < 8; i++) {
+      if (col < 8) w->Ac[i * 8 + col] = rhs[i], w->A[i * 8 + col] = rhs[8 + i];
+      else w->Bc[i * 2 + col - 8] = rhs[i], w->B[i * 2 + col - 8] = rhs[8 + i];
+    }
   }
-  double mu = (warm && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
-  SET_SMOOTHING(mu);
+  double HA[64], HB[16];
+  for (int i = 0; i < 8; i++) {
+    for (int j = 0; j < 8; j++) {
+      double v = 0;
+      for (int l = 0; l < 8; l++) v += L[k].Hc[i * 8 + l] * w->Ac[l * 8 + j];
+      HA[i * 8 + j] = v;
+    }
+    for (int j = 0; j < 2; j++) {
+      double v = 0;
+      for (int l = 0; l < 8; l++) v += L[k].Hc[i * 8 + l] * w->Bc[l * 2 + j];
+      HB[i * 2 + j] = v;
+    }
+  }
+  for (int i = 0; i < 8; i++)
+    for (int j = 0; j < 8; j++) {
+      double v = 0;
+      for (int l = 0; l < 8; l++) v += w->Ac[l * 8 + i] * HA[l * 8 + j];
+      w->Q[i * 8 + j] = v;
+    }
+  for (int i = 0; i < 2; i++) {
+    for (int j = 0; j < 8; j++) {
+      double v = 0;
+      for (int l = 0; l < 8; l++) v += w->Bc[l * 2 + i] * HA[l * 8 + j];
+      w->S[i * 8 + j] = v;
+    }
+    for (int j = 0; j < 2; j++) {
+      double v = 0;
+      for (int l = 0; l < 8; l++) v += w->Bc[l * 2 + i] * HB[l * 2 + j];
+      w->R[i * 2 + j] = v;
+    }
+    w->R[i * 2 + i] += L[k].Du[i];
+  }
+  /* node terms of x_k come from slot k-1 (x_0 is fixed: dx_0 = 0, nothing to add) */
+  if (k > 0)
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) w->Q[i * 8 + j] += L[k - 1].Hxp[i * 8 + j];
+  return 0;
+}
+/* right-hand-side part: bc, b from the residuals (rG1, rG2), q, r from the gradients */
+static void condense_rhs(ipws* s, int k) {
+  stage_ws* w = &s->W[k];
+  slot_lin* L = s->L;
+  double rhs[16], Hb[8];
+  for (int i = 0; i < 8; i++) rhs[i] = -L[k].rG1[i], rhs[8 + i] = -L[k].rG2[i];
+  lu_solve(w->M, 16, w->piv, rhs);
+  for (int i = 0; i < 8; i++) w->bc[i] = rhs[i], w->b[i] = rhs[8 + i];
+  for (int i = 0; i < 8; i++) {
+    double v = L[k].gc[i];
+    for (int l = 0; l < 8; l++) v += L[k].Hc[i * 8 + l] * w->bc[l];
+    Hb[i] = v;
+  }
+  for (int i = 0; i < 8; i++) {
+    double v = 0;
+    for (int l = 0; l < 8; l++) v += w->Ac[l * 8 + i] * Hb[l];
+    w->q[i] = v;
+  }
+  for (int i = 0; i < 2; i++) {
+    double v = L[k].gub[i];
+    for (int l = 0; l < 8; l++) v += w->Bc[l * 2 + i] * Hb[l];
+    w->r[i] = v;
+  }
+  if (k > 0)
+    for (int i = 0; i < 8; i++) w->q[i] += L[k - 1].gxp[i];
+}
+
+/* Riccati sweep on the state (x_k, v_k = u_{k-1}).  rhs_only = 0: matrices and vectors, returns 0 when some Huu is
+ * not positive definite (inertia test).  rhs_only = 1: the vectors kff, pp, pv again for new b, q, r (the factors K,
+ * Kv, P, Pxv, Hux, Huu^-1 of the last full sweep are kept): what a second-order correction costs. */
+static int riccati_sweep(ipws* s, double delta_w, int rhs_only) {
+  const int N = s->N;
+  const ltompc_params* p = s->p;
+  const iterate_t* it = &s->it;
+  slot_lin* L = s->L;
+  double P[64], Pxv[16], Pvv[4], pp[8], pv[2];
+  for (int i = 0; i < 64; i++) P[i] = L[N - 1].Hxp[i];
+  for (int i = 0; i < 8; i++) P[i * 8 + i] += delta_w, pp[i] = L[N - 1].gxp[i];
+  memset(Pxv, 0, sizeof Pxv), memset(Pvv, 0, sizeof Pvv), memset(pv, 0, sizeof pv);
+  for (int k = N - 1; k >= 0; k--) {
+    stage_ws* w = &s->W[k];
+    const double* v = k ? it->u + (k - 1) * NU : s->uprev;
+    double r2[2] = {2 * p->r_du[0], 2 * p->r_du[1]};
+    double Pb[8]; /* P b + p */
+    for (int i = 0; i < 8; i++) {
+      double v2 = pp[i];
+      for (int l = 0; l < 8; l++) v2 += P[i * 8 + l] * w->b[l];
+      Pb[i] = v2;
+    }
+    double gu[2], gx[8];
+    for (int i = 0; i < 2; i++) {
+      double v2 = w->r[i] + r2[i] * (it->u[k * NU + i] - v[i]) + pv[i];
+      for (int l = 0; l < 8; l++) v2 += w->B[l * 2 + i] * Pb[l] + Pxv[l * 2 + i] * w->b[l];
+      gu[i] = v2;
+    }
+    for (int i = 0; i < 8; i++) {
+      double v2 = w->q[i];
+      for (int l = 0; l < 8; l++) v2 += w->A[l * 8 + i] * Pb[l];
+      gx[i] = v2;
+    }
+    if (!rhs_only) {
+      double PA[64], PB[16];
+      for (int i = 0; i < 8; i++) {
+        for (int j = 0; j < 8; j++) {
+          double v2 = 0;
+          for (int l = 0; l < 8; l++) v2 += P[i * 8 + l] * w->A[l * 8 + j];
+          PA[i * 8 + j] = v2;
+        }
+        for (int j = 0; j < 2; j++) {
+          double v2 = 0;
+          for (int l = 0; l < 8; l++) v2 += P[i * 8 + l] * w->B[l * 2 + j];
+          PB[i * 2 + j] = v2;
+        }
+      }
+      double Huu[4], Hxx[64];
+      for (int i = 0; i < 2; i++) {
+        for (int j = 0; j < 2; j++) {
+          double v2 = w->R[i * 2 + j] + Pvv[i * 2 + j];
+          for (int l = 0; l < 8; l++) v2 += w->B[l * 2 + i] * PB[l * 2 + j] + w->B[l * 2 + i] * Pxv[l * 2 + j] + Pxv[l * 2 + i] * w->B[l * 2 + j];
+          Huu[i * 2 + j] = v2;
+        }
+        Huu[i * 2 + i] += r2[i] + delta_w;
+        for (int j = 0; j < 8; j++) {
+          double v2 = w->S[i * 8 + j];
+          for (int l = 0; l < 8; l++) v2 += w->B[l * 2 + i] * PA[l * 8 + j] + Pxv[l * 2 + i] * w->A[l * 8 + j];
+          w->Hux[i * 8 + j] = v2;
+        }
+      }
+      for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 8; j++) {
+          double v2 = w->Q[i * 8 + j] + (i == j ? delta_w : 0.0);
+          for (int l = 0; l < 8; l++) v2 += w->A[l * 8 + i] * PA[l * 8 + j];
+          Hxx[i * 8 + j] = v2;
+        }
+      /* Huu must be positive definite (inertia test of the reduced Hessian) */
+      double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+      if (!(Huu[0] > 0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det)) return 0;
+      w->Hi[0] = Huu[3] / det, w->Hi[1] = -Huu[1] / det, w->Hi[2] = -Huu[2] / det, w->Hi[3] = Huu[0] / det;
+      for (int i = 0; i < 2; i++) {
+        for (int j = 0; j < 8; j++) w->K[i * 8 + j] = -(w->Hi[i * 2 + 0] * w->Hux[0 * 8 + j] + w->Hi[i * 2 + 1] * w->Hux[1 * 8 + j]);
+        for (int j = 0; j < 2; j++) w->Kv[i * 2 + j] = w->Hi[i * 2 + j] * r2[j]; /* -Huu^-1 Huv, Huv = -diag(r2) */
+      }
+      for (int i = 0; i < 8; i++) {
+        for (int j = 0; j < 8; j++) w->P[i * 8 + j] = Hxx[i * 8 + j] + w->Hux[0 * 8 + i] * w->K[0 * 8 + j] + w->Hux[1 * 8 + i] * w->K[1 * 8 + j];
+        for (int j = 0; j < 2; j++) w->Pxv[i * 2 + j] = w->Hux[0 * 8 + i] * w->Kv[0 * 2 + j] + w->Hux[1 * 8 + i] * w->Kv[1 * 2 + j];
+      }
+      for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++) w->Pvv[i * 2 + j] = (i == j ? r2[i] : 0.0) - r2[i] * w->Kv[i * 2 + j];
+      for (int i = 0; i < 8; i++) /* symmetrise P */
+        for (int j = 0; j < i; j++) w->P[i * 8 + j] = w->P[j * 8 + i] = 0.5 * (w->P[i * 8 + j] + w->P[j * 8 + i]);
+    }
+    for (int i = 0; i < 2; i++) w->kff[i] = -(w->Hi[i * 2 + 0] * gu[0] + w->Hi[i * 2 + 1] * gu[1]);
+    /* cost-to-go of (x_k, v_k) */
+    double gv[2] = {-r2[0] * (it->u[k * NU + 0] - v[0]), -r2[1] * (it->u[k * NU + 1] - v[1])};
+    for (int i = 0; i < 8; i++) w->pp[i] = gx[i] + w->Hux[0 * 8 + i] * w->kff[0] + w->Hux[1 * 8 + i] * w->kff[1];
+    for (int i = 0; i < 2; i++) w->pv[i] = gv[i] - r2[i] * w->kff[i];
+    memcpy(P, w->P, sizeof P), memcpy(Pxv, w->Pxv, sizeof Pxv), memcpy(Pvv, w->Pvv, sizeof Pvv);
+    memcpy(pp, w->pp, sizeof pp), memcpy(pv, w->pv, sizeof pv);
+  }
+  return 1;
+}
+
+/* forward sweep + recovery of dc and the collocation multipliers */
+static void forward_recover(ipws* s, double delta_w) {
+  const int N = s->N;
+  slot_lin* L = s->L;
+  double *dx = s->dx, *dc = s->dc, *du = s->du;
+  memset(dx, 0, sizeof(double) * NX);
+  double dv[2] = {0, 0};
+  for (int k = 0; k < N; k++) {
+    stage_ws* w = &s->W[k];
+    for (int i = 0; i < 2; i++) {
+      double v = w->kff[i] + w->Kv[i * 2 + 0] * dv[0] + w->Kv[i * 2 + 1] * dv[1];
+      for (int j = 0; j < 8; j++) v += w->K[i * 8 + j] * dx[k * NX + j];
+      du[k * NU + i] = v;
+    }
+    for (int i = 0; i < 8; i++) {
+      double v = w->b[i] + w->B[i * 2] * du[k * NU] + w->B[i * 2 + 1] * du[k * NU + 1];
+      double sc = w->bc[i] + w->Bc[i * 2] * du[k * NU] + w->Bc[i * 2 + 1] * du[k * NU + 1];
+      for (int j = 0; j < 8; j++) v += w->A[i * 8 + j] * dx[k * NX + j], sc += w->Ac[i * 8 + j] * dx[k * NX + j];
+      dx[(k + 1) * NX + i] = v, dc[k * NX + i] = sc;
+    }
+    dv[0] = du[k * NU], dv[1] = du[k * NU + 1];
+  }
+  for (int k = 0; k < N; k++) {
+    stage_ws* w = &s->W[k];
+    /* costate pi_{k+1} = dV_{k+1}/dx_{k+1} ; V_N = terminal node block */
+    double pi[8], rhs[16];
+    for (int i = 0; i < 8; i++) {
+      double v;
+      if (k + 1 < N) {
+        stage_ws* wn = &s->W[k + 1];
+        v = wn->pp[i] + wn->Pxv[i * 2] * du[k * NU] + wn->Pxv[i * 2 + 1] * du[k * NU + 1];
+        for (int j = 0; j < 8; j++) v += wn->P[i * 8 + j] * dx[(k + 1) * NX + j];
+      } else {
+        v = L[N - 1].gxp[i] + delta_w * dx[N * NX + i];
+        for (int j = 0; j < 8; j++) v += L[N - 1].Hxp[i * 8 + j] * dx[N * NX + j];
+      }
+      pi[i] = v;
+    }
+    for (int i = 0; i < 8; i++) {
+      double v = L[k].gc[i];
+      for (int j = 0; j < 8; j++) v += L[k].Hc[i * 8 + j] * dc[k * NX + j];
+      rhs[i] = -v, rhs[8 + i] = -pi[i];
+    }
+    lu_solve_t(w->M, 16, w->piv, rhs);
+    memcpy(s->nl1 + k * NX, rhs, sizeof(double) * 8), memcpy(s->nl2 + k * NX, rhs + 8, sizeof(double) * 8);
+  }
+}
+
+/* slack / inequality-multiplier steps for the residuals L->rI, fraction to the boundary, directional derivative of
+ * the barrier objective */
+static void slack_steps(ipws* s, double tau, double* a_pri_out, double* a_dua_out, double* gphi_out) {
+  const int N = s->N, ni = s->ni;
+  const bounds_t* bd = &s->bd;
+  const ltompc_params* p = s->p;
+  iterate_t* it = &s->it;
+  slot_lin* L = s->L;
+  const double mu = s->mu, rho = it->rho;
+  double *dx = s->dx, *dc = s->dc, *du = s->du, *dt = s->dt, *dnu = s->dnu, *de = s->de;
+  double a_pri = 1.0, a_dua = 1.0, gphi_d = 0.0;
+  for (int k = 0; k < N; k++) {
+    int m = 0;
+    const double* v = k ? it->u + (k - 1) * NU : s->uprev;
+    const double* dvk = k ? du + (k - 1) * NU : NULL;
+    for (int i = 0; i < NU; i++) {
+      double ddu = du[k * NU + i] - (dvk ? dvk[i] : 0.0);
+      gphi_d += 2 * p->r_du[i] * (it->u[k * NU + i] - v[i]) * ddu;
+    }
+    for (int a = 0; a < NX; a++) gphi_d += L[k].gcost[a] * dx[(k + 1) * NX + a];
+    for (int i = 0; i < ni; i++, m++) {
+      if (!L[k].act[m]) {
+        dt[k * MAXI + m] = dnu[k * MAXI + m] = 0;
+        if (m >= ni - NNL) de[k * NNL + m - (ni - NNL)] = 0;
+        continue;
+      }
+      double gd;
+      if (m < bd->n_ub) gd = bd->ub_sgn[m] * du[k * NU + bd->ub_idx[m]];
+      else if (m < bd->n_ub + bd->n_xb) gd = bd->xb_sgn[m - bd->n_ub] * dc[k * NX + bd->xb_idx[m - bd->n_ub]];
+      else if (m < bd->n_ub + 2 * bd->n_xb) gd = bd->xb_sgn[m - bd->n_ub - bd->n_xb] * dx[(k + 1) * NX + bd->xb_idx[m - bd->n_ub - bd->n_xb]];
+      else {
+        int q = m - bd->n_ub - 2 * bd->n_xb;
+        gd = 0;
+        for (int a = 0; a < NX; a++) gd += L[k].gnl[q][a] * dx[(k + 1) * NX + a];
+      }
+      double t = it->t[k * MAXI + m], nu = it->nu[k * MAXI + m];
+      double dtt = -L[k].rI[m] - gd;
+      double dn = (mu - nu * dtt) / t - nu;
+      if (rho > 0 && m >= ni - NNL) {
+        int q = m - (ni - NNL);
+        double e = it->e[k * NNL + q], z = rho - nu;
+        double Sg = 1.0 / (t / nu + e / z);
+        dn = Sg * (gd + (L[k].rI[m] + e - t) + mu / nu - mu / z);
+        dtt = mu / nu - t - (t / nu) * dn;
+        double dee = mu / z - e + (e / z) * dn;
+        de[k * NNL + q] = dee;
+        if (dee < 0) a_pri = fmin(a_pri, -tau * e / dee);
+        if (dn > 0) a_dua = fmin(a_dua, tau * z / dn);
+        gphi_d += rho * dee - mu * dee / e;
+      }
+      dt[k * MAXI + m] = dtt, dnu[k * MAXI + m] = dn;
+      if (dtt < 0 && -tau * t / dtt < a_pri && getenv("ORACLE_TRACE2")) fprintf(stderr, "     limit k=%d m=%d t=%.3e dt=%.3e h=%.3e gd=%.3e\n", k, m, t, dtt, L[k].h[m], gd);
+      if (dtt < 0) a_pri = fmin(a_pri, -tau * t / dtt);
+      if (dn < 0) a_dua = fmin(a_dua, -tau * nu / dn);
+      gphi_d -= mu * dtt / t;
+    }
+  }
+  *a_pri_out = a_pri, *a_dua_out = a_dua, *gphi_out = gphi_d;
+}
+
+/* trial point it + alpha * (dx, dc, du, dt, de) into tr */
+static void make_trial(ipws* s, double alpha) {
+  const int N = s->N, ni = s->ni;
+  iterate_t *it = &s->it, *tr = &s->tr;
+  for (int k = 0; k <= N; k++)
+    for (int i = 0; i < NX; i++) tr->x[k * NX + i] = it->x[k * NX + i] + alpha * s->dx[k * NX + i];
+  for (int k = 0; k < N; k++) {
+    for (int i = 0; i < NX; i++) tr->c[k * NX + i] = it->c[k * NX + i] + alpha * s->dc[k * NX + i];
+    for (int i = 0; i < NU; i++) tr->u[k * NU + i] = it->u[k * NU + i] + alpha * s->du[k * NU + i];
+    for (int m = 0; m < ni; m++) tr->t[k * MAXI + m] = it->t[k * MAXI + m] + alpha * s->dt[k * MAXI + m];
+    for (int q = 0; q < NNL; q++) tr->e[k * NNL + q] = it->e[k * NNL + q] + alpha * s->de[k * NNL + q];
+  }
+}
+
+/* slacks, inequality multipliers (and elastic variables) of every slot from the primal point: t = max(-h, bound_push),
+ * nu = mu / t; softened track constraints: see the comment inside */
+static void init_slacks(ipws* s) {
+  const int N = s->N, ni = s->ni;
+  iterate_t* it = &s->it;
+  const ltompc_options* o = s->o;
+  const double mu = s->mu, rho = it->rho;
   for (int k = 0; k < N; k++) {
     double h[MAXI];
     int act[MAXI];
-    slot_ineq(p, T, &bd, N, k, it.u + k * NU, it.c + k * NX, it.x + (k + 1) * NX, NULL, h, act);
+    slot_ineq(s->p, s->T, &s->bd, N, k, it->u + k * NU, it->c + k * NX, it->x + (k + 1) * NX, NULL, h, act);
     for (int m = 0; m < ni; m++) {
       if (rho > 0 && m >= ni - NNL) {
         /* softened track constraint: slack and multiplier as for the hard one (t = max(-g, bound_push), nu = mu / t,
@@ -663,14 +979,78 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
          * as a large elastic variable with nu ~ rho that the barrier lets go of only slowly), the elastic variable
          * on the central path of its own pair: e (rho - nu) = mu.  t >= 2 mu / rho keeps nu <= rho / 2. */
         double t = fmax(fmax(-h[m], o->bound_push), 2 * mu / rho), nu = mu / t;
-        it.t[k * MAXI + m] = t, it.nu[k * MAXI + m] = nu, it.e[k * NNL + m - (ni - NNL)] = mu / (rho - nu);
+        it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu, it->e[k * NNL + m - (ni - NNL)] = mu / (rho - nu);
         continue;
       }
       double t = -h[m] > o->bound_push ? -h[m] : o->bound_push;
-      it.t[k * MAXI + m] = t;
-      it.nu[k * MAXI + m] = getenv("ORACLE_NU1") ? 1.0 : mu / t;
+      it->t[k * MAXI + m] = t;
+      it->nu[k * MAXI + m] = mu / t;
     }
   }
+}
+
+static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
+                     const double* uprev, int warm, double* X, double* C, double* U, double* L1, double* L2,
+                     double* Tout, double* NUout, solve_stats* st) {
+  ipws S;
+  ipws* s = &S;
+  memset(s, 0, sizeof S);
+  s->p = p, s->o = o, s->N = N, s->hdt = o->t_step, s->uprev = uprev;
+  build_bounds(p, &s->bd);
+  const bounds_t* bd = &s->bd;
+  const int ni = s->ni = bd->ni;
+  const double hdt = o->t_step;
+  tables_t Tl = *T0;
+  tables_t* T = &Tl;
+  s->T = T;
+#define SMOOTHING(mu_) ((o->smooth_scale > 0 || o->smooth_eps_min > 0) ? fmax(o->smooth_eps_min, o->smooth_scale * (mu_)) : 0.0)
+  Tl.eps_mu = 0.0;
+  s->it = it_alloc(N), s->tr = it_alloc(N);
+  iterate_t *it = &s->it, *tr = &s->tr;
+  it->rho = tr->rho = o->soft_rho;
+  s->de = calloc((size_t)N * NNL, sizeof(double));
+  s->L = malloc(sizeof(slot_lin) * (size_t)N);
+  s->W = malloc(sizeof(stage_ws) * (size_t)N);
+  slot_lin* L = s->L;
+  s->dx = calloc((size_t)(N + 1) * NX, sizeof(double));
+  s->dc = calloc((size_t)N * NX, sizeof(double));
+  s->du = calloc((size_t)N * NU, sizeof(double));
+  s->nl1 = calloc((size_t)N * NX, sizeof(double));
+  s->nl2 = calloc((size_t)N * NX, sizeof(double));
+  s->dt = calloc((size_t)N * MAXI, sizeof(double));
+  s->dnu = calloc((size_t)N * MAXI, sizeof(double));
+  double *dx = s->dx, *dc = s->dc, *du = s->du, *nl1 = s->nl1, *nl2 = s->nl2, *dt = s->dt, *dnu = s->dnu, *de = s->de;
+  /* second-order correction: residuals of a trial point */
+  double* sG1 = calloc((size_t)N * NX, sizeof(double));
+  double* sG2 = calloc((size_t)N * NX, sizeof(double));
+  double* sR = calloc((size_t)N * MAXI, sizeof(double));
+
+  /* ---- initial point: do_mpc set_initial_guess (all slots = x0, u = 0) or the previous solution ---- */
+  if (!warm) {
+    for (int k = 0; k <= N; k++) memcpy(it->x + k * NX, x0, sizeof(double) * NX);
+    for (int k = 0; k < N; k++) memcpy(it->c + k * NX, x0, sizeof(double) * NX);
+  } else {
+    memcpy(it->x, X, sizeof(double) * (size_t)(N + 1) * NX);
+    memcpy(it->c, C, sizeof(double) * (size_t)N * NX);
+    memcpy(it->u, U, sizeof(double) * (size_t)N * NU);
+    memcpy(it->l1, L1, sizeof(double) * (size_t)N * NX);
+    memcpy(it->l2, L2, sizeof(double) * (size_t)N * NX);
+    if (o->warm_shift) { /* option: shift the previous solution by one interval (last interval repeated) */
+      for (int k = 0; k + 1 < N; k++) {
+        memcpy(it->x + k * NX, X + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it->c + k * NX, C + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it->u + k * NU, U + (k + 1) * NU, sizeof(double) * NU);
+        memcpy(it->l1 + k * NX, L1 + (k + 1) * NX, sizeof(double) * NX);
+        memcpy(it->l2 + k * NX, L2 + (k + 1) * NX, sizeof(double) * NX);
+      }
+      memcpy(it->x + (N - 1) * NX, X + N * NX, sizeof(double) * NX);
+    }
+    memcpy(it->x, x0, sizeof(double) * NX); /* node 0 is the measured state */
+  }
+  double mu = (warm && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
+  s->mu = mu;
+  Tl.eps_s = SMOOTHING(mu);
+  init_slacks(s);
 
   /* filter */
   double filt_th[FILTER_MAX], filt_ph[FILTER_MAX];
@@ -679,33 +1059,37 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   double delta_w_last = 0.0;
   int status = LTOMPC_STATUS_MAX_ITER, iter = 0, n_acc = 0;
   double E0 = INFINITY, obj = 0;
-  st->n_reg = 0, st->n_lsfail = 0;
+  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0;
   double force_reg = 0.0;
+  /* restoration (elastic mode): 0 = not entered, 1 = solving the elastic problem, 2 = back on the hard constraints */
+  int resto = 0;
+  const int resto_allowed = o->resto_rho > 0 && !(o->soft_rho > 0);
 
   double eps_next = Tl.eps_s;
   int n_tiny = 0;
   for (iter = 0;; iter++) {
+    double rho = it->rho;
     /* table smoothing follows the barrier parameter with a lag of one iteration (so that one linearisation
      * serves the whole iteration, also when mu is reduced in it); the filter restarts when it changes */
     if (eps_next != Tl.eps_s) Tl.eps_s = eps_next, nfilt = 0, theta0 = -1;
     /* ---- linearise ---- */
-    for (int k = 0; k < N; k++) linearise_slot(p, o, T, &bd, &it, k, mu, &L[k]);
+    for (int k = 0; k < N; k++) linearise_slot(p, o, T, bd, it, k, mu, &L[k]);
     /* ---- KKT error (IPOPT eq. (5)/(6)) ---- */
-    double rd = 0, rp = 0, rc_mu = 0, rc_0 = 0, sum_mult = 0;
+    double rd = 0, rp = 0, rc_mu = 0, rc_0 = 0, sum_mult = 0, e_max = 0;
     int rd_k = -1, rd_v = -1;
     int n_mult = 0;
-    obj = cost_val(p, T, it.x, 0);
+    obj = cost_val(p, T, it->x, 0);
     for (int k = 0; k < N; k++) {
-      const double *l1 = it.l1 + k * NX, *l2 = it.l2 + k * NX;
-      const double* v = k ? it.u + (k - 1) * NU : uprev;
+      const double *l1 = it->l1 + k * NX, *l2 = it->l2 + k * NX;
+      const double* v = k ? it->u + (k - 1) * NU : uprev;
       obj += L[k].cost;
       if (rho > 0 && L[k].act[ni - 1])
-        for (int q = 0; q < NNL; q++) obj += rho * it.e[k * NNL + q];
+        for (int q = 0; q < NNL; q++) obj += rho * it->e[k * NNL + q], e_max = fmax(e_max, it->e[k * NNL + q]);
       for (int a = 0; a < NX; a++) {
         double rcx = L[k].dc_dual[a] + 4.5 * l2[a];
         double rxp = L[k].dxp_dual[a] - 0.5 * l1[a];
         for (int i = 0; i < NX; i++) rcx += L[k].E1[i * 8 + a] * l1[i], rxp += L[k].E2[i * 8 + a] * l2[i];
-        if (k + 1 < N) rxp += 2 * it.l1[(k + 1) * NX + a] - 2 * it.l2[(k + 1) * NX + a];
+        if (k + 1 < N) rxp += 2 * it->l1[(k + 1) * NX + a] - 2 * it->l2[(k + 1) * NX + a];
         if (fabs(rcx) > rd) rd_k = k, rd_v = 100 + a;
         if (fabs(rxp) > rd && fabs(rxp) > fabs(rcx)) rd_k = k, rd_v = a;
         rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
@@ -714,21 +1098,21 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       }
       n_mult += 2 * NX;
       for (int i = 0; i < NU; i++) {
-        double uk = it.u[k * NU + i];
+        double uk = it->u[k * NU + i];
         obj += p->r_du[i] * (uk - v[i]) * (uk - v[i]);
         double ru = L[k].du_dual[i] + 2 * p->r_du[i] * (uk - v[i]) + hdt * (l1[6 + i] + l2[6 + i]);
-        if (k + 1 < N) ru -= 2 * p->r_du[i] * (it.u[(k + 1) * NU + i] - uk);
+        if (k + 1 < N) ru -= 2 * p->r_du[i] * (it->u[(k + 1) * NU + i] - uk);
         rd = fmax(rd, fabs(ru));
       }
       for (int m = 0; m < ni; m++)
         if (L[k].act[m]) {
-          double t = it.t[k * MAXI + m], nu = it.nu[k * MAXI + m];
+          double t = it->t[k * MAXI + m], nu = it->nu[k * MAXI + m];
           rp = fmax(rp, fabs(L[k].h[m] + t));
           rc_mu = fmax(rc_mu, fabs(t * nu - mu));
           rc_0 = fmax(rc_0, fabs(t * nu));
           sum_mult += fabs(nu), n_mult++;
           if (rho > 0 && m >= ni - NNL) {
-            double ez = it.e[k * NNL + m - (ni - NNL)] * (rho - nu);
+            double ez = it->e[k * NNL + m - (ni - NNL)] * (rho - nu);
             rc_mu = fmax(rc_mu, fabs(ez - mu)), rc_0 = fmax(rc_0, fabs(ez));
             sum_mult += fabs(rho - nu), n_mult++;
           }
@@ -737,11 +1121,30 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     double s_d = fmax(o->s_max, sum_mult / n_mult) / o->s_max;
     E0 = fmax(fmax(rd / s_d, rp), rc_0 / s_d);
     double Emu = fmax(fmax(rd / s_d, rp), rc_mu / s_d);
-    if (!isfinite(E0)) { status = LTOMPC_STATUS_NUMERICAL; break; }
-    if (E0 <= o->tol) { status = LTOMPC_STATUS_SOLVED; break; }
-    if (E0 <= o->acceptable_tol) { if (++n_acc >= o->acceptable_iter) { status = LTOMPC_STATUS_ACCEPTABLE; break; } }
-    else n_acc = 0;
-    if (iter >= o->max_iter) { status = LTOMPC_STATUS_MAX_ITER; break; }
+    int term = -1;
+    if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
+    else if (E0 <= o->tol) term = LTOMPC_STATUS_SOLVED;
+    else {
+      if (E0 <= o->acceptable_tol) { if (++n_acc >= o->acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE; }
+      else n_acc = 0;
+      if (term < 0 && iter >= o->max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    }
+    if (resto == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {
+      /* The elastic problem has converged.  All elastic variables at (numerically) zero: its solution is a KKT point
+       * of the hard-constrained NLP with the same multipliers (nu < rho); back to the hard constraints, where the
+       * termination test is repeated on the hard problem's own KKT error.  Otherwise the violation cannot be removed
+       * locally: a stationary point of the infeasibility. */
+      const double e_tol = term == LTOMPC_STATUS_SOLVED ? o->tol : o->acceptable_tol;
+      if (e_max <= e_tol) {
+        resto = 2, it->rho = tr->rho = 0.0;
+        n_acc = 0, nfilt = 0, theta0 = -1;
+        if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d elastic problem converged, e_max %.2e: back to the hard constraints\n", iter, e_max);
+        iter--; /* (this pass only switched the problem: not an iteration) */
+        continue;
+      }
+      term = LTOMPC_STATUS_INFEASIBLE;
+    }
+    if (term >= 0) { status = term; break; }
     /* ---- barrier update (monotone, IPOPT eq. (7)); slot derivatives depend on mu only via gradients ---- */
     int mu_changed = 0;
     while (Emu <= o->kappa_eps * mu && mu > o->mu_min) {
@@ -752,96 +1155,26 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       for (int k = 0; k < N; k++)
         for (int m = 0; m < ni; m++)
           if (L[k].act[m]) {
-            rcm = fmax(rcm, fabs(it.t[k * MAXI + m] * it.nu[k * MAXI + m] - mu));
-            if (rho > 0 && m >= ni - NNL) rcm = fmax(rcm, fabs(it.e[k * NNL + m - (ni - NNL)] * (rho - it.nu[k * MAXI + m]) - mu));
+            rcm = fmax(rcm, fabs(it->t[k * MAXI + m] * it->nu[k * MAXI + m] - mu));
+            if (rho > 0 && m >= ni - NNL) rcm = fmax(rcm, fabs(it->e[k * NNL + m - (ni - NNL)] * (rho - it->nu[k * MAXI + m]) - mu));
           }
       Emu = fmax(Emu, rcm / s_d);
     }
+    s->mu = mu;
     if (mu_changed) {
-      eps_next = (o->smooth_scale > 0 || o->smooth_eps_min > 0) ? fmax(o->smooth_eps_min, o->smooth_scale * mu) : 0.0;
-      for (int k = 0; k < N; k++) linearise_slot(p, o, T, &bd, &it, k, mu, &L[k]);
+      eps_next = SMOOTHING(mu);
+      for (int k = 0; k < N; k++) slot_gradients(bd, it, k, mu, &L[k]);
       nfilt = 0, theta0 = -1; /* filter reset */
     }
     double tau = fmax(o->tau_min, 1.0 - mu);
 
-    /* ---- condensing of the collocation point: [dc; dx+] = M^-1 (-[G1;G2] - [2;-2] dx - [Bu;Bu] du) ---- */
+    /* ---- condensing of the collocation point ---- */
     for (int k = 0; k < N; k++) {
-      stage_ws* w = &W[k];
-      double* M = w->M;
-      memset(M, 0, sizeof w->M);
-      for (int i = 0; i < 8; i++)
-        for (int j = 0; j < 8; j++) {
-          M[i * 16 + j] = L[k].E1[i * 8 + j];
-          M[(8 + i) * 16 + 8 + j] = L[k].E2[i * 8 + j];
-        }
-      for (int i = 0; i < 8; i++) M[i * 16 + 8 + i] = -0.5, M[(8 + i) * 16 + i] = 4.5;
-      if (lu_factor(M, 16, w->piv)) { status = LTOMPC_STATUS_NUMERICAL; goto done; }
-      for (int col = 0; col < 11; col++) {
-        double rhs[16];
-        for (int i = 0; i < 8; i++) {
-          if (col < 8) rhs[i] = (i == col) ? -2.0 : 0.0, rhs[8 + i] = (i == col) ? 2.0 : 0.0;
-          else if (col < 10) rhs[i] = rhs[8 + i] = (i == 6 + (col - 8)) ? -hdt : 0.0;
-          else rhs[i] = -L[k].G1[i], rhs[8 + i] = -L[k].G2[i];
-        }
-        lu_solve(M, 16, w->piv, rhs);
-        for (int i = 0; i < 8; i++) {
-          if (col < 8) w->Ac[i * 8 + col] = rhs[i], w->A[i * 8 + col] = rhs[8 + i];
-          else if (col < 10) w->Bc[i * 2 + col - 8] = rhs[i], w->B[i * 2 + col - 8] = rhs[8 + i];
-          else w->bc[i] = rhs[i], w->b[i] = rhs[8 + i];
-        }
-      }
-      /* project the c-block of the QP onto (x_k, u_k) */
-      double HA[64], HB[16], Hb[8];
-      for (int i = 0; i < 8; i++) {
-        for (int j = 0; j < 8; j++) {
-          double s = 0;
-          for (int l = 0; l < 8; l++) s += L[k].Hc[i * 8 + l] * w->Ac[l * 8 + j];
-          HA[i * 8 + j] = s;
-        }
-        for (int j = 0; j < 2; j++) {
-          double s = 0;
-          for (int l = 0; l < 8; l++) s += L[k].Hc[i * 8 + l] * w->Bc[l * 2 + j];
-          HB[i * 2 + j] = s;
-        }
-        double s = L[k].gc[i];
-        for (int l = 0; l < 8; l++) s += L[k].Hc[i * 8 + l] * w->bc[l];
-        Hb[i] = s;
-      }
-      for (int i = 0; i < 8; i++) {
-        for (int j = 0; j < 8; j++) {
-          double s = 0;
-          for (int l = 0; l < 8; l++) s += w->Ac[l * 8 + i] * HA[l * 8 + j];
-          w->Q[i * 8 + j] = s;
-        }
-        double s = 0;
-        for (int l = 0; l < 8; l++) s += w->Ac[l * 8 + i] * Hb[l];
-        w->q[i] = s;
-      }
-      for (int i = 0; i < 2; i++) {
-        for (int j = 0; j < 8; j++) {
-          double s = 0;
-          for (int l = 0; l < 8; l++) s += w->Bc[l * 2 + i] * HA[l * 8 + j];
-          w->S[i * 8 + j] = s;
-        }
-        for (int j = 0; j < 2; j++) {
-          double s = 0;
-          for (int l = 0; l < 8; l++) s += w->Bc[l * 2 + i] * HB[l * 2 + j];
-          w->R[i * 2 + j] = s;
-        }
-        double s = L[k].gub[i];
-        for (int l = 0; l < 8; l++) s += w->Bc[l * 2 + i] * Hb[l];
-        w->r[i] = s;
-        w->R[i * 2 + i] += L[k].Du[i];
-      }
-      /* node terms of x_k come from slot k-1 (x_0 is fixed: dx_0 = 0, nothing to add) */
-      if (k > 0)
-        for (int i = 0; i < 8; i++) {
-          w->q[i] += L[k - 1].gxp[i];
-          for (int j = 0; j < 8; j++) w->Q[i * 8 + j] += L[k - 1].Hxp[i * 8 + j];
-        }
+      if (condense_matrices(s, k)) { status = LTOMPC_STATUS_NUMERICAL; goto done; }
+      condense_rhs(s, k);
     }
 
-    /* ---- Riccati sweep on the state (x_k, v_k = u_{k-1}); retried with Hessian regularisation ---- */
+    /* ---- Riccati sweep, retried with Hessian regularisation ---- */
     double delta_w = force_reg;
     /* Deviation from IPOPT's Algorithm IC: while the previous iteration needed a regularisation larger than
      * DW_KEEP the first attempt already uses delta_w_last / 3 instead of 0 (every attempt is a full sweep here;
@@ -849,139 +1182,20 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
      * returns to exactly 0 below DW_KEEP, so the final Newton iterations are unregularised. */
     if (delta_w == 0.0 && delta_w_last > DW_KEEP) delta_w = delta_w_last / 3.0;
     int tries = 0;
-    for (;;) {
-      int ok = 1;
-      double P[64], Pxv[16], Pvv[4], pp[8], pv[2];
-      for (int i = 0; i < 64; i++) P[i] = L[N - 1].Hxp[i];
-      for (int i = 0; i < 8; i++) P[i * 8 + i] += delta_w, pp[i] = L[N - 1].gxp[i];
-      memset(Pxv, 0, sizeof Pxv), memset(Pvv, 0, sizeof Pvv), memset(pv, 0, sizeof pv);
-      for (int k = N - 1; k >= 0 && ok; k--) {
-        stage_ws* w = &W[k];
-        const double* v = k ? it.u + (k - 1) * NU : uprev;
-        double r2[2] = {2 * p->r_du[0], 2 * p->r_du[1]};
-        double PA[64], PB[16], Pb[8]; /* P A, P B, P b + p */
-        for (int i = 0; i < 8; i++) {
-          for (int j = 0; j < 8; j++) {
-            double s = 0;
-            for (int l = 0; l < 8; l++) s += P[i * 8 + l] * w->A[l * 8 + j];
-            PA[i * 8 + j] = s;
-          }
-          for (int j = 0; j < 2; j++) {
-            double s = 0;
-            for (int l = 0; l < 8; l++) s += P[i * 8 + l] * w->B[l * 2 + j];
-            PB[i * 2 + j] = s;
-          }
-          double s = pp[i];
-          for (int l = 0; l < 8; l++) s += P[i * 8 + l] * w->b[l];
-          Pb[i] = s;
-        }
-        double Huu[4], Hux[16], gu[2], Hxx[64], gx[8];
-        for (int i = 0; i < 2; i++) {
-          for (int j = 0; j < 2; j++) {
-            double s = w->R[i * 2 + j] + Pvv[i * 2 + j];
-            for (int l = 0; l < 8; l++) s += w->B[l * 2 + i] * PB[l * 2 + j] + w->B[l * 2 + i] * Pxv[l * 2 + j] + Pxv[l * 2 + i] * w->B[l * 2 + j];
-            Huu[i * 2 + j] = s;
-          }
-          Huu[i * 2 + i] += r2[i] + delta_w;
-          for (int j = 0; j < 8; j++) {
-            double s = w->S[i * 8 + j];
-            for (int l = 0; l < 8; l++) s += w->B[l * 2 + i] * PA[l * 8 + j] + Pxv[l * 2 + i] * w->A[l * 8 + j];
-            Hux[i * 8 + j] = s;
-          }
-          double s = w->r[i] + r2[i] * (it.u[k * NU + i] - v[i]) + pv[i];
-          for (int l = 0; l < 8; l++) s += w->B[l * 2 + i] * Pb[l] + Pxv[l * 2 + i] * w->b[l];
-          gu[i] = s;
-        }
-        for (int i = 0; i < 8; i++) {
-          for (int j = 0; j < 8; j++) {
-            double s = w->Q[i * 8 + j] + (i == j ? delta_w : 0.0);
-            for (int l = 0; l < 8; l++) s += w->A[l * 8 + i] * PA[l * 8 + j];
-            Hxx[i * 8 + j] = s;
-          }
-          double s = w->q[i];
-          for (int l = 0; l < 8; l++) s += w->A[l * 8 + i] * Pb[l];
-          gx[i] = s;
-        }
-        /* Huu must be positive definite (inertia test of the reduced Hessian) */
-        double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
-        if (!(Huu[0] > 0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det)) { ok = 0; break; }
-        double Hi[4] = {Huu[3] / det, -Huu[1] / det, -Huu[2] / det, Huu[0] / det};
-        for (int i = 0; i < 2; i++) {
-          for (int j = 0; j < 8; j++) w->K[i * 8 + j] = -(Hi[i * 2 + 0] * Hux[0 * 8 + j] + Hi[i * 2 + 1] * Hux[1 * 8 + j]);
-          for (int j = 0; j < 2; j++) w->Kv[i * 2 + j] = Hi[i * 2 + j] * r2[j]; /* -Huu^-1 Huv, Huv = -diag(r2) */
-          w->kff[i] = -(Hi[i * 2 + 0] * gu[0] + Hi[i * 2 + 1] * gu[1]);
-        }
-        /* cost-to-go of (x_k, v_k) */
-        double gv[2] = {-r2[0] * (it.u[k * NU + 0] - v[0]), -r2[1] * (it.u[k * NU + 1] - v[1])};
-        for (int i = 0; i < 8; i++) {
-          for (int j = 0; j < 8; j++) P[i * 8 + j] = Hxx[i * 8 + j] + Hux[0 * 8 + i] * w->K[0 * 8 + j] + Hux[1 * 8 + i] * w->K[1 * 8 + j];
-          for (int j = 0; j < 2; j++) Pxv[i * 2 + j] = Hux[0 * 8 + i] * w->Kv[0 * 2 + j] + Hux[1 * 8 + i] * w->Kv[1 * 2 + j];
-          pp[i] = gx[i] + Hux[0 * 8 + i] * w->kff[0] + Hux[1 * 8 + i] * w->kff[1];
-        }
-        for (int i = 0; i < 2; i++) {
-          for (int j = 0; j < 2; j++) Pvv[i * 2 + j] = (i == j ? r2[i] : 0.0) - r2[i] * w->Kv[i * 2 + j];
-          pv[i] = gv[i] - r2[i] * w->kff[i];
-        }
-        /* symmetrise P */
-        for (int i = 0; i < 8; i++)
-          for (int j = 0; j < i; j++) P[i * 8 + j] = P[j * 8 + i] = 0.5 * (P[i * 8 + j] + P[j * 8 + i]);
-        memcpy(w->P, P, sizeof P), memcpy(w->Pxv, Pxv, sizeof Pxv), memcpy(w->Pvv, Pvv, sizeof Pvv);
-        memcpy(w->pp, pp, sizeof pp), memcpy(w->pv, pv, sizeof pv);
-      }
-      if (ok) break;
+    while (!riccati_sweep(s, delta_w, 0)) {
       /* IPOPT-style inertia correction schedule (Waechter-Biegler Alg. IC) */
       if (delta_w == 0.0) delta_w = delta_w_last == 0.0 ? o->delta_w_first : fmax(1e-20, delta_w_last / 3.0);
       else delta_w *= (delta_w_last == 0.0 ? 100.0 : 8.0);
       st->n_reg++;
-      if (++tries > 40 || delta_w > 1e20) { status = LTOMPC_STATUS_NUMERICAL; goto done; }
+      if (++tries > 40 || delta_w > 1e20) {
+        status = LTOMPC_STATUS_NUMERICAL;
+        goto done;
+      }
     }
     if (delta_w > 0) delta_w_last = delta_w;
     if (delta_w_last <= DW_KEEP) delta_w_last = 0.0;
 
-    /* ---- forward sweep + recovery of dc and the collocation multipliers ---- */
-    memset(dx, 0, sizeof(double) * NX);
-    {
-      double dv[2] = {0, 0};
-      for (int k = 0; k < N; k++) {
-        stage_ws* w = &W[k];
-        for (int i = 0; i < 2; i++) {
-          double s = w->kff[i] + w->Kv[i * 2 + 0] * dv[0] + w->Kv[i * 2 + 1] * dv[1];
-          for (int j = 0; j < 8; j++) s += w->K[i * 8 + j] * dx[k * NX + j];
-          du[k * NU + i] = s;
-        }
-        for (int i = 0; i < 8; i++) {
-          double s = w->b[i] + w->B[i * 2] * du[k * NU] + w->B[i * 2 + 1] * du[k * NU + 1];
-          double sc = w->bc[i] + w->Bc[i * 2] * du[k * NU] + w->Bc[i * 2 + 1] * du[k * NU + 1];
-          for (int j = 0; j < 8; j++) s += w->A[i * 8 + j] * dx[k * NX + j], sc += w->Ac[i * 8 + j] * dx[k * NX + j];
-          dx[(k + 1) * NX + i] = s, dc[k * NX + i] = sc;
-        }
-        dv[0] = du[k * NU], dv[1] = du[k * NU + 1];
-      }
-      for (int k = 0; k < N; k++) {
-        stage_ws* w = &W[k];
-        /* costate pi_{k+1} = dV_{k+1}/dx_{k+1} ; V_N = terminal node block */
-        double pi[8], rhs[16];
-        for (int i = 0; i < 8; i++) {
-          double s;
-          if (k + 1 < N) {
-            stage_ws* wn = &W[k + 1];
-            s = wn->pp[i] + wn->Pxv[i * 2] * du[k * NU] + wn->Pxv[i * 2 + 1] * du[k * NU + 1];
-            for (int j = 0; j < 8; j++) s += wn->P[i * 8 + j] * dx[(k + 1) * NX + j];
-          } else {
-            s = L[N - 1].gxp[i] + delta_w * dx[N * NX + i];
-            for (int j = 0; j < 8; j++) s += L[N - 1].Hxp[i * 8 + j] * dx[N * NX + j];
-          }
-          pi[i] = s;
-        }
-        for (int i = 0; i < 8; i++) {
-          double s = L[k].gc[i];
-          for (int j = 0; j < 8; j++) s += L[k].Hc[i * 8 + j] * dc[k * NX + j];
-          rhs[i] = -s, rhs[8 + i] = -pi[i];
-        }
-        lu_solve_t(w->M, 16, w->piv, rhs);
-        memcpy(nl1 + k * NX, rhs, sizeof(double) * 8), memcpy(nl2 + k * NX, rhs + 8, sizeof(double) * 8);
-      }
-    }
+    forward_recover(s, delta_w);
     if (getenv("ORACLE_CHECK")) { /* residual of the linear KKT system the sweep is supposed to solve */
       double ra = 0, rb = 0, rcc = 0, rdd = 0, re = 0;
       for (int k = 0; k < N; k++) {
@@ -999,153 +1213,193 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           }
           ra = fmax(ra, fabs(a)), rb = fmax(rb, fabs(b)), rcc = fmax(rcc, fabs(c)), rdd = fmax(rdd, fabs(d));
         }
-        const double* v = k ? it.u + (k - 1) * NU : uprev;
+        const double* v = k ? it->u + (k - 1) * NU : uprev;
         for (int i = 0; i < 2; i++) {
           double r2 = 2 * p->r_du[i];
-          double e = (L[k].Du[i] + r2 + delta_w) * du[k * NU + i] + L[k].gub[i] + r2 * (it.u[k * NU + i] - v[i]) + hdt * (nl1[k * NX + 6 + i] + nl2[k * NX + 6 + i]);
+          double e = (L[k].Du[i] + r2 + delta_w) * du[k * NU + i] + L[k].gub[i] + r2 * (it->u[k * NU + i] - v[i]) + hdt * (nl1[k * NX + 6 + i] + nl2[k * NX + 6 + i]);
           if (k > 0) e -= r2 * du[(k - 1) * NU + i];
-          if (k + 1 < N) e += r2 * du[k * NU + i] - r2 * du[(k + 1) * NU + i] - r2 * (it.u[(k + 1) * NU + i] - it.u[k * NU + i]);
+          if (k + 1 < N) e += r2 * du[k * NU + i] - r2 * du[(k + 1) * NU + i] - r2 * (it->u[(k + 1) * NU + i] - it->u[k * NU + i]);
           re = fmax(re, fabs(e));
         }
       }
       fprintf(stderr, "   KKT-lin residuals: G1 %.2e G2 %.2e c %.2e x+ %.2e u %.2e\n", ra, rb, rcc, rdd, re);
     }
-    /* ---- slack / inequality-multiplier steps and fraction-to-boundary ---- */
-    double a_pri = 1.0, a_dua = 1.0, gphi_d = 0.0;
-    for (int k = 0; k < N; k++) {
-      int m = 0;
-      const double* v = k ? it.u + (k - 1) * NU : uprev;
-      const double* dvk = k ? du + (k - 1) * NU : NULL;
-      for (int i = 0; i < NU; i++) {
-        double ddu = du[k * NU + i] - (dvk ? dvk[i] : 0.0);
-        gphi_d += 2 * p->r_du[i] * (it.u[k * NU + i] - v[i]) * ddu;
-      }
-      for (int a = 0; a < NX; a++) gphi_d += L[k].gcost[a] * dx[(k + 1) * NX + a];
-      for (int i = 0; i < ni; i++, m++) {
-        if (!L[k].act[m]) { dt[k * MAXI + m] = dnu[k * MAXI + m] = 0; continue; }
-        double gd;
-        if (m < bd.n_ub) gd = bd.ub_sgn[m] * du[k * NU + bd.ub_idx[m]];
-        else if (m < bd.n_ub + bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub] * dc[k * NX + bd.xb_idx[m - bd.n_ub]];
-        else if (m < bd.n_ub + 2 * bd.n_xb) gd = bd.xb_sgn[m - bd.n_ub - bd.n_xb] * dx[(k + 1) * NX + bd.xb_idx[m - bd.n_ub - bd.n_xb]];
-        else {
-          int q = m - bd.n_ub - 2 * bd.n_xb;
-          gd = 0;
-          for (int a = 0; a < NX; a++) gd += L[k].gnl[q][a] * dx[(k + 1) * NX + a];
-        }
-        double t = it.t[k * MAXI + m], nu = it.nu[k * MAXI + m];
-        double dtt = -(L[k].h[m] + t) - gd;
-        double dn = (mu - nu * dtt) / t - nu;
-        if (rho > 0 && m >= ni - NNL) {
-          int q = m - (ni - NNL);
-          double e = it.e[k * NNL + q], z = rho - nu;
-          double Sg = 1.0 / (t / nu + e / z);
-          dn = Sg * (gd + (L[k].h[m] + e) + mu / nu - mu / z);
-          dtt = mu / nu - t - (t / nu) * dn;
-          double dee = mu / z - e + (e / z) * dn;
-          de[k * NNL + q] = dee;
-          if (dee < 0) a_pri = fmin(a_pri, -tau * e / dee);
-          if (dn > 0) a_dua = fmin(a_dua, tau * z / dn);
-          gphi_d += rho * dee - mu * dee / e;
-        }
-        dt[k * MAXI + m] = dtt, dnu[k * MAXI + m] = dn;
-        if (dtt < 0 && -tau * t / dtt < a_pri && getenv("ORACLE_TRACE2")) fprintf(stderr, "     limit k=%d m=%d t=%.3e dt=%.3e h=%.3e gd=%.3e\n", k, m, t, dtt, L[k].h[m], gd);
-        if (dtt < 0) a_pri = fmin(a_pri, -tau * t / dtt);
-        if (dn < 0) a_dua = fmin(a_dua, -tau * nu / dn);
-        gphi_d -= mu * dtt / t;
-      }
-    }
-    /* ---- filter line search over alpha = a_pri * 2^-l ---- */
+    double a_pri, a_dua, gphi_d;
+    slack_steps(s, tau, &a_pri, &a_dua, &gphi_d);
+
+    /* ---- filter line search over alpha = a_pri * 2^-l, second-order correction after a rejected full step ---- */
     double th0, co0, sl0;
-    eval_measures(p, o, T, &bd, &it, uprev, &th0, &co0, &sl0);
+    eval_residuals(p, o, T, bd, it, uprev, NULL, NULL, NULL, &th0, &co0, &sl0);
     double ph0 = co0 - mu * sl0;
     if (theta0 < 0) {
       theta0 = th0;
       theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
       nfilt = 0;
     }
-    const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0;
-    int accepted = 0;
+    const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0, kappa_soc = 0.99;
+    int accepted = 0, used_soc = 0;
     double alpha = a_pri;
+    /* acceptance test of IPOPT's filter line search for a trial point with measures (th, ph); a_test: the step size
+     * in the switching / Armijo conditions (the uncorrected one also for corrected steps) */
+#define ACCEPTABLE(th, ph, a_test, ok_out)                                                                      \
+  do {                                                                                                          \
+    ok_out = 0;                                                                                                 \
+    if (!isfinite(th) || !isfinite(ph) || th > theta_max) break;                                                \
+    int in_filter_ = 0;                                                                                         \
+    for (int f = 0; f < nfilt; f++)                                                                             \
+      if (th >= filt_th[f] && ph >= filt_ph[f]) { in_filter_ = 1; break; }                                      \
+    if (in_filter_) break;                                                                                      \
+    int sw_ = (gphi_d < 0) && ((a_test) * pow(-gphi_d, s_ph) > dlt * pow(th0, s_th));                           \
+    int armijo_ = ph <= ph0 + eta_ph * (a_test) * gphi_d;                                                       \
+    int ok_;                                                                                                    \
+    if (th0 <= theta_min && sw_) ok_ = armijo_;                                                                 \
+    else ok_ = (th <= (1 - g_th) * th0) || (ph <= ph0 - g_ph * th0);                                            \
+    if (!ok_) break;                                                                                            \
+    if (!(sw_ && armijo_)) { /* augment filter */                                                               \
+      if (nfilt == FILTER_MAX) { memmove(filt_th, filt_th + 1, sizeof(double) * (FILTER_MAX - 1)); memmove(filt_ph, filt_ph + 1, sizeof(double) * (FILTER_MAX - 1)); nfilt--; } \
+      filt_th[nfilt] = (1 - g_th) * th0, filt_ph[nfilt] = ph0 - g_ph * th0, nfilt++;                            \
+    }                                                                                                           \
+    ok_out = 1;                                                                                                 \
+  } while (0)
     for (int l = 0; l < o->n_linesearch; l++, alpha *= 0.5) {
-      for (int k = 0; k <= N; k++)
-        for (int i = 0; i < NX; i++) tr.x[k * NX + i] = it.x[k * NX + i] + alpha * dx[k * NX + i];
-      for (int k = 0; k < N; k++) {
-        for (int i = 0; i < NX; i++) tr.c[k * NX + i] = it.c[k * NX + i] + alpha * dc[k * NX + i];
-        for (int i = 0; i < NU; i++) tr.u[k * NU + i] = it.u[k * NU + i] + alpha * du[k * NU + i];
-        for (int m = 0; m < ni; m++) tr.t[k * MAXI + m] = it.t[k * MAXI + m] + alpha * dt[k * MAXI + m];
-        for (int q = 0; q < NNL; q++) tr.e[k * NNL + q] = it.e[k * NNL + q] + alpha * de[k * NNL + q];
-      }
+      make_trial(s, alpha);
       double th, co, sl;
-      eval_measures(p, o, T, &bd, &tr, uprev, &th, &co, &sl);
+      eval_residuals(p, o, T, bd, tr, uprev, sG1, sG2, sR, &th, &co, &sl);
       double ph = co - mu * sl;
-      if (!isfinite(th) || !isfinite(ph) || th > theta_max) continue;
-      int in_filter = 0;
-      for (int f = 0; f < nfilt; f++)
-        if (th >= filt_th[f] && ph >= filt_ph[f]) { in_filter = 1; break; }
-      if (in_filter) continue;
-      int sw = (gphi_d < 0) && (alpha * pow(-gphi_d, s_ph) > dlt * pow(th0, s_th));
-      int armijo = ph <= ph0 + eta_ph * alpha * gphi_d;
-      int ok;
-      if (th0 <= theta_min && sw) ok = armijo;
-      else ok = (th <= (1 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
-      if (!ok) continue;
-      if (!(sw && armijo)) { /* augment filter */
-        if (nfilt == FILTER_MAX) { memmove(filt_th, filt_th + 1, sizeof(double) * (FILTER_MAX - 1)); memmove(filt_ph, filt_ph + 1, sizeof(double) * (FILTER_MAX - 1)); nfilt--; }
-        filt_th[nfilt] = (1 - g_th) * th0, filt_ph[nfilt] = ph0 - g_ph * th0, nfilt++;
+      ACCEPTABLE(th, ph, alpha, accepted);
+      if (accepted) {
+        if (getenv("ORACLE_LSHIST")) fprintf(stderr, "LS %d\n", l);
+        break;
       }
-      accepted = 1;
-      if (getenv("ORACLE_LSHIST")) fprintf(stderr, "LS %d\n", l);
-      break;
+      if (l == 0 && o->max_soc > 0 && isfinite(th) && th >= th0) {
+        /* ---- second-order correction (Waechter & Biegler 2006, A-5.5 .. A-5.9): the full step was rejected and did not
+         *      reduce the infeasibility.  c_soc = alpha c(x) + c(x + alpha d); same KKT matrix, new right-hand side.
+         *      The uncorrected step is kept aside: the backtracking continues with it when the correction fails. */
+        const size_t nX = (size_t)(N + 1) * NX, nC = (size_t)N * NX, nU = (size_t)N * NU, nT = (size_t)N * MAXI, nE = (size_t)N * NNL;
+        double* keep = malloc(sizeof(double) * (nX + 3 * nC + nU + 2 * nT + nE));
+        double *k_dx = keep, *k_dc = k_dx + nX, *k_du = k_dc + nC, *k_l1 = k_du + nU, *k_l2 = k_l1 + nC, *k_dt = k_l2 + nC, *k_dn = k_dt + nT, *k_de = k_dn + nT;
+        memcpy(k_dx, dx, sizeof(double) * nX), memcpy(k_dc, dc, sizeof(double) * nC), memcpy(k_du, du, sizeof(double) * nU);
+        memcpy(k_l1, nl1, sizeof(double) * nC), memcpy(k_l2, nl2, sizeof(double) * nC);
+        memcpy(k_dt, dt, sizeof(double) * nT), memcpy(k_dn, dnu, sizeof(double) * nT), memcpy(k_de, de, sizeof(double) * nE);
+        double th_old = th0, a_soc = alpha, a_dua_soc = a_dua;
+        int soc_ok = 0;
+        for (int c = 0; c < o->max_soc; c++) {
+          /* c_soc <- a_soc c_soc + c(trial)  (c_soc = c(x) before the first correction) */
+          for (int k = 0; k < N; k++) {
+            for (int i = 0; i < NX; i++)
+              L[k].rG1[i] = a_soc * L[k].rG1[i] + sG1[k * NX + i], L[k].rG2[i] = a_soc * L[k].rG2[i] + sG2[k * NX + i];
+            for (int m = 0; m < ni; m++)
+              if (L[k].act[m]) L[k].rI[m] = a_soc * L[k].rI[m] + sR[k * MAXI + m];
+            slot_gradients(bd, it, k, mu, &L[k]);
+          }
+          for (int k = 0; k < N; k++) condense_rhs(s, k);
+          riccati_sweep(s, delta_w, 1);
+          forward_recover(s, delta_w);
+          double gphi_soc;
+          slack_steps(s, tau, &a_soc, &a_dua_soc, &gphi_soc);
+          make_trial(s, a_soc);
+          double th_s, co_s, sl_s;
+          eval_residuals(p, o, T, bd, tr, uprev, sG1, sG2, sR, &th_s, &co_s, &sl_s);
+          double ph_s = co_s - mu * sl_s;
+          st->n_soc++;
+          ACCEPTABLE(th_s, ph_s, alpha, soc_ok);
+          if (getenv("ORACLE_TRACE")) fprintf(stderr, "     soc %d: a_soc %.4f theta %.3e -> %.3e (start %.3e) phi %.6e ok %d\n", c, a_soc, th, th_s, th0, ph_s, soc_ok);
+          if (soc_ok || !isfinite(th_s) || th_s > kappa_soc * th_old) break;
+          th_old = th_s;
+        }
+        if (soc_ok) {
+          accepted = 1, used_soc = 1, alpha = a_soc, a_dua = a_dua_soc;
+          free(keep);
+          break;
+        }
+        /* back to the uncorrected step and residuals */
+        memcpy(dx, k_dx, sizeof(double) * nX), memcpy(dc, k_dc, sizeof(double) * nC), memcpy(du, k_du, sizeof(double) * nU);
+        memcpy(nl1, k_l1, sizeof(double) * nC), memcpy(nl2, k_l2, sizeof(double) * nC);
+        memcpy(dt, k_dt, sizeof(double) * nT), memcpy(dnu, k_dn, sizeof(double) * nT), memcpy(de, k_de, sizeof(double) * nE);
+        free(keep);
+        for (int k = 0; k < N; k++) {
+          memcpy(L[k].rG1, L[k].G1, sizeof L[k].G1), memcpy(L[k].rG2, L[k].G2, sizeof L[k].G2);
+          for (int m = 0; m < ni; m++) L[k].rI[m] = L[k].act[m] ? L[k].h[m] + it->t[k * MAXI + m] : 0.0;
+          slot_gradients(bd, it, k, mu, &L[k]);
+        }
+      }
     }
+    (void)used_soc;
     if (!accepted) {
-      /* no restoration phase here: retry this iterate with a (larger) forced regularisation; after a few
-       * failures take the smallest step and reset the filter so that the iteration cannot stall */
       st->n_lsfail++;
+      if (resto_allowed && resto == 0) {
+      enter_resto:
+        /* ---- restoration phase, as an elastic mode: the track constraints get elastic variables that
+         *      cost resto_rho each; equality multipliers, slacks and the barrier parameter start again at the current
+         *      primal point.  (IPOPT: min rho ||c(x)||_1 + zeta/2 ||D(x - x_R)||^2 over all constraints, then back to
+         *      the original problem; here the objective stays, so the elastic problem's solution with e = 0 already
+         *      is the solution.) */
+        resto = 1, st->n_resto++;
+        it->rho = tr->rho = o->resto_rho;
+        memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
+        mu = s->mu = o->mu_init;
+        Tl.eps_s = eps_next = SMOOTHING(mu);
+        init_slacks(s);
+        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+        if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d -> restoration (elastic mode, rho %.0f)\n", iter, o->resto_rho);
+        continue;
+      }
+      /* no (further) restoration: retry this iterate with a (larger) forced regularisation; after a few
+       * failures take the smallest step and reset the filter so that the iteration cannot stall */
       if (o->max_ls_fail > 0 && st->n_lsfail >= o->max_ls_fail) { status = LTOMPC_STATUS_STALLED; break; }
       if (force_reg < 1e4) { force_reg = force_reg == 0 ? 1e-2 : force_reg * 100; continue; }
       nfilt = 0;
       alpha = a_pri * pow(0.5, o->n_linesearch - 1);
     }
     force_reg = 0.0;
-    /* IPOPT would enter restoration and report local infeasibility; here: stop after stall_iter tiny steps */
+    /* consecutive tiny steps: IPOPT would enter restoration */
     n_tiny = alpha <= 1e-3 ? n_tiny + 1 : 0;
-    if (o->stall_iter > 0 && n_tiny >= o->stall_iter) { status = LTOMPC_STATUS_STALLED; break; }
+    if (o->stall_iter > 0 && n_tiny >= o->stall_iter) {
+      if (resto_allowed && resto == 0) goto enter_resto;
+      status = LTOMPC_STATUS_STALLED;
+      break;
+    }
     if (getenv("ORACLE_TRACE"))
       fprintf(stderr, "it %3d mu %.2e E0 %.3e rd %.2e rp %.2e rc %.2e th0 %.3e ph0 %.6e a_pri %.3f a_dua %.3f alpha %.4f dw %.1e gphid %.3e acc %d obj %.6f u0 %.8f %.8f rdk %d rdv %d mu_k %.3e s_k %.4f\n",
-              iter, mu, E0, rd, rp, rc_0, th0, ph0, a_pri, a_dua, alpha, delta_w, gphi_d, accepted, obj, it.u[0], it.u[1], rd_k, rd_v, rd_k >= 0 ? it.x[(rd_k + 1) * NX + 2] : 0.0, rd_k >= 0 ? it.x[(rd_k + 1) * NX] : 0.0);
+              iter, mu, E0, rd, rp, rc_0, th0, ph0, a_pri, a_dua, alpha, delta_w, gphi_d, accepted, obj, it->u[0], it->u[1], rd_k, rd_v, rd_k >= 0 ? it->x[(rd_k + 1) * NX + 2] : 0.0, rd_k >= 0 ? it->x[(rd_k + 1) * NX] : 0.0);
     /* ---- take the step ---- */
     for (int k = 1; k <= N; k++)
-      for (int i = 0; i < NX; i++) it.x[k * NX + i] += alpha * dx[k * NX + i];
+      for (int i = 0; i < NX; i++) it->x[k * NX + i] += alpha * dx[k * NX + i];
     for (int k = 0; k < N; k++) {
       for (int i = 0; i < NX; i++) {
-        it.c[k * NX + i] += alpha * dc[k * NX + i];
-        it.l1[k * NX + i] += alpha * (nl1[k * NX + i] - it.l1[k * NX + i]);
-        it.l2[k * NX + i] += alpha * (nl2[k * NX + i] - it.l2[k * NX + i]);
+        it->c[k * NX + i] += alpha * dc[k * NX + i];
+        it->l1[k * NX + i] += alpha * (nl1[k * NX + i] - it->l1[k * NX + i]);
+        it->l2[k * NX + i] += alpha * (nl2[k * NX + i] - it->l2[k * NX + i]);
       }
-      for (int i = 0; i < NU; i++) it.u[k * NU + i] += alpha * du[k * NU + i];
+      for (int i = 0; i < NU; i++) it->u[k * NU + i] += alpha * du[k * NU + i];
       for (int m = 0; m < ni; m++) {
         if (!L[k].act[m]) continue;
-        double t = it.t[k * MAXI + m] + alpha * dt[k * MAXI + m];
-        double nu = it.nu[k * MAXI + m] + a_dua * dnu[k * MAXI + m];
+        double t = it->t[k * MAXI + m] + alpha * dt[k * MAXI + m];
+        double nu = it->nu[k * MAXI + m] + a_dua * dnu[k * MAXI + m];
         /* IPOPT eq. (16): keep nu within [mu/(kS t), kS mu/t], kS = 1e10 */
         double lo = mu / (1e10 * t), hi = 1e10 * mu / t;
-        it.t[k * MAXI + m] = t, it.nu[k * MAXI + m] = nu < lo ? lo : (nu > hi ? hi : nu);
-        if (rho > 0 && m >= ni - NNL) it.e[k * NNL + m - (ni - NNL)] += alpha * de[k * NNL + m - (ni - NNL)];
+        it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu < lo ? lo : (nu > hi ? hi : nu);
+        if (rho > 0 && m >= ni - NNL) it->e[k * NNL + m - (ni - NNL)] += alpha * de[k * NNL + m - (ni - NNL)];
       }
     }
   }
 done:
-  memcpy(X, it.x, sizeof(double) * (size_t)(N + 1) * NX);
-  memcpy(C, it.c, sizeof(double) * (size_t)N * NX);
-  memcpy(U, it.u, sizeof(double) * (size_t)N * NU);
-  memcpy(L1, it.l1, sizeof(double) * (size_t)N * NX);
-  memcpy(L2, it.l2, sizeof(double) * (size_t)N * NX);
+  memcpy(X, it->x, sizeof(double) * (size_t)(N + 1) * NX);
+  memcpy(C, it->c, sizeof(double) * (size_t)N * NX);
+  memcpy(U, it->u, sizeof(double) * (size_t)N * NU);
+  memcpy(L1, it->l1, sizeof(double) * (size_t)N * NX);
+  memcpy(L2, it->l2, sizeof(double) * (size_t)N * NX);
   if (Tout && NUout)
     for (int k = 0; k < N; k++)
-      for (int m = 0; m < ni; m++) Tout[k * ni + m] = it.t[k * MAXI + m], NUout[k * ni + m] = it.nu[k * MAXI + m];
+      for (int m = 0; m < ni; m++) Tout[k * ni + m] = it->t[k * MAXI + m], NUout[k * ni + m] = it->nu[k * MAXI + m];
   st->status = status, st->iters = iter, st->kkt = E0, st->obj = obj, st->mu = mu;
-  it_free(&it), it_free(&tr);
-  free(L), free(W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu), free(de);
+  st->viol = 0.0;
+  if (it->rho > 0)
+    for (int k = 0; k + 1 < N; k++)
+      for (int q = 0; q < NNL; q++) st->viol = fmax(st->viol, it->e[k * NNL + q]);
+  it_free(it), it_free(tr);
+  free(s->L), free(s->W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu), free(de);
+  free(sG1), free(sG2), free(sR);
   return 0;
 }
 
@@ -1172,6 +1426,7 @@ void oracle_default_options(ltompc_options* o) {
   o->t_step = 0.1, o->tol = 1e-8, o->acceptable_tol = 1e-6, o->mu_init = 0.1, o->mu_min = 1e-9;
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
+  o->resto_rho = 1000.0, o->max_soc = 0;
   o->warm_reset_on_fail = 1; /* applied by the caller (oracle.py solve(prev_status=...)): this file sees one solve at a time */
 }
 
@@ -1264,7 +1519,7 @@ int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const d
 
 /* Batched solve.  Arrays are batch-major: X: B x (N+1) x 8, C: B x N x 8, U: B x N x 2, L1/L2: B x N x 8
  * (in: warm start if warm != 0; out: solution).  stats: B x 5 doubles (status, iters, kkt, obj, mu) +
- * 2 ints packed as doubles (n_reg, n_lsfail) => 7 doubles per instance. */
+ * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol => 10 doubles per instance. */
 int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const double* tab, int nt, int N, int B,
                        const double* x0, const double* uprev, int warm, double* X, double* C, double* U,
                        double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout) {
@@ -1284,8 +1539,9 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
               C + (size_t)b * N * NX, U + (size_t)b * N * NU, L1 + (size_t)b * N * NX, L2 + (size_t)b * N * NX,
               Tout ? Tout + (size_t)b * N * ni0 : NULL, NUout ? NUout + (size_t)b * N * ni0 : NULL, &st);
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
-    double* s = stats + (size_t)b * 7;
+    double* s = stats + (size_t)b * 10;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;
+    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol;
   }
   return 0;
 }

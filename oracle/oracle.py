@@ -27,9 +27,9 @@ class Params(C.Structure):
 class Options(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
-        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho")] + [
+        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho", "resto_rho")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("latency_mode", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("latency_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -152,14 +152,15 @@ class Oracle:
             L1, L2 = np.zeros((B, N, 8)), np.zeros((B, N, 8))
         else:
             X, Cc, U, L1, L2 = (np.ascontiguousarray(warm[k], float).copy() for k in ("X", "C", "U", "L1", "L2"))
-        u0, st = np.zeros((B, 2)), np.zeros((B, 7))
+        u0, st = np.zeros((B, 2)), np.zeros((B, 10))
         ni = int(lib().oracle_num_ineq(C.byref(self.p)))
         Tt, Nu = np.zeros((B, N, ni)), np.zeros((B, N, ni))
         lib().oracle_solve_batch(C.byref(self.p), C.byref(self.o), _p(self.tab), self.nt, int(N), int(B), _p(x0),
                                  _p(uprev), int(warm is not None), _p(X), _p(Cc), _p(U), _p(L1), _p(L2), _p(u0),
                                  _p(st), int(nthreads), _p(Tt), _p(Nu))
         return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
-                    kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int))
+                    kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int),
+                    n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9])
 
 
 def num_threads() -> int:
