@@ -12,6 +12,7 @@ namespace ltompc {
 constexpr int FILTER_MAX = 16;
 constexpr double DW_KEEP = 1e-5;  // regularisation below this is dropped to exactly 0
 constexpr int MAX_LS = 12;
+constexpr double ELASTIC_CP_VIOL = 0.1;  // [m] violation of a track constraint above which its elastic variable starts on the central path
 
 // fields of the stage-QP buffer written by k_eval and read by k_riccati
 enum : int {

@@ -109,6 +109,13 @@ __device__ __forceinline__ void init_slot_slacks(const Consts& K, const Work& W,
       // t >= 2 mu / rho keeps nu <= rho / 2.
       t = fmax(t, 2.0 * mu / rho);
       e = mu / (rho - mu / t);
+      if (gv[q] > ELASTIC_CP_VIOL) {
+        // grossly violated (here the Newton steps would have to shrink t by rho / nu ~ 1e4 at 1 % of a step per
+        // iteration): on the central path of the elastic pair instead, e - t = g, t nu = mu, e (rho - nu) = mu
+        const double g = gv[q], bq = rho * g - 2.0 * mu;
+        t = (-bq + sqrt(bq * bq + 4.0 * rho * mu * g)) / (2.0 * rho);
+        e = g + t;
+      }
     }
     PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;
   }

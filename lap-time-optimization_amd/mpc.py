@@ -9,7 +9,7 @@
     controller.mpc.x0 = x0                      same                  src/mpc.py:117
     controller.mpc.set_initial_guess()          same                  src/mpc.py:118
     u0 = controller.mpc.make_step(x0)           same, (8,1) -> (2,1)  src/mpc.py:142   <- the hot path
-    mpc.simulator.Simulator(model).simulator    same, make_step(u0)   src/mpc/simulator.py:14-20, mpc.py:143
+    mpc.simulator.Simulator(model).simulator    same, make_step(u0)   src/mpc/simulator.py:14-20, mpc.py:114,143
 
 A counterpart of the reference's closed-loop driver (src/mpc.py:86-173) is `closed_loop()` below.
 """
@@ -132,34 +132,58 @@ class Controller:
                 raise ValueError("penalty_term_cons must be positive")
             o.soft_rho = float(penalty_term_cons)
         self.solver = BatchedMPC(model.track.tables, n_horizon=n_horizon, batch=batch, params=p, options=o, device=device)
+        model._solver = self.solver  # (Simulator(model) runs the plant on the same handle)
         self.mpc = _MPC(self.solver)
 
 
 class _Sim:
-    def __init__(self, solver: BatchedMPC, n_sub: int):
-        self._solver, self._n_sub, self.x0 = solver, n_sub, None
+    """The subset of do_mpc.simulator.Simulator that src/mpc.py touches: attribute x0, make_step(u0) -> y."""
+
+    def __init__(self, model: VehicleModel, n_sub: int):
+        self._model, self._n_sub, self.x0 = model, n_sub, None
+        self._solver = None
+
+    def _plant(self, batch: int) -> BatchedMPC:
+        # the plant step runs on the device through a solver handle: the controller's (registered on the model by
+        # Controller) when it has the same batch size, else a minimal handle of its own
+        if self._solver is None or self._solver.B != batch:
+            shared = getattr(self._model, "_solver", None)
+            if shared is not None and shared.B == batch:
+                self._solver = shared
+            else:
+                self._solver = BatchedMPC(self._model.track.tables, n_horizon=2, batch=batch, params=self._model.params)
+        return self._solver
 
     def make_step(self, u0):
         u0 = np.asarray(u0, dtype=np.float64)
         single = u0.shape == (2, 1)
-        x = np.asarray(self.x0, dtype=np.float64).reshape(self._solver.B, 8)
-        xn = self._solver.plant_step(x, u0.reshape(self._solver.B, 2), self._n_sub)
+        if self.x0 is None:
+            raise AssertionError("set simulator.x0 before make_step()")
+        u = u0.reshape(-1, 2)
+        solver = self._plant(u.shape[0])
+        x = np.asarray(self.x0, dtype=np.float64).reshape(solver.B, 8)
+        xn = solver.plant_step(x, u, self._n_sub)
         self.x0 = xn.reshape(8, 1) if single else xn
         return self.x0
 
 
 class Simulator:
-    """src/mpc/simulator.py:14-20: plant with t_step = 0.1 (plotting part of the reference is out of scope)."""
+    """src/mpc/simulator.py:14-20: `Simulator(model).simulator` is the plant with t_step = 0.1 (the plotting part of the
+    reference's class is out of scope).  Takes the VehicleModel like the reference (mpc.py:114); a Controller is accepted
+    too (its model is used)."""
 
-    def __init__(self, controller: Controller, n_sub: int = 400):
-        self.simulator = _Sim(controller.solver, n_sub)
+    def __init__(self, model, n_sub: int = 400):
+        if isinstance(model, Controller):
+            model = model.model
+        self.model = model
+        self.simulator = _Sim(model, n_sub)
 
 
 def closed_loop(controller: Controller, x0, steps: int, out_json: str | None = None):
     """Counterpart of the reference's loop (src/mpc.py:117-159): make_step -> plant -> identity estimator.
     Returns dict(x, y, u, Fy, alpha) with the reference's sim_results.json schema."""
     x0 = np.reshape(np.asarray(x0, dtype=np.float64), (-1, 1))
-    sim = Simulator(controller).simulator
+    sim = Simulator(controller.model).simulator
     sim.x0 = x0
     controller.mpc.x0 = x0
     controller.mpc.set_initial_guess()

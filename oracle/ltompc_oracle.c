@@ -635,6 +635,7 @@ typedef struct {
 } solve_stats;
 
 #define FILTER_MAX 64
+#define ELASTIC_CP_VIOL 0.1 /* [m] violation of a track constraint above which its elastic variable starts on the central path */
 #define DW_KEEP 1e-5
 
 /* everything one solve works on */
@@ -980,6 +981,13 @@ static void init_slacks(ipws* s) {
          * on the central path of its own pair: e (rho - nu) = mu.  t >= 2 mu / rho keeps nu <= rho / 2. */
         double t = fmax(fmax(-h[m], o->bound_push), 2 * mu / rho), nu = mu / t;
         it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu, it->e[k * NNL + m - (ni - NNL)] = mu / (rho - nu);
+        if (h[m] > ELASTIC_CP_VIOL) {
+          /* grossly violated (here the Newton steps would have to shrink t by rho / nu ~ 1e4 at 1 % of a step per
+           * iteration): on the central path of the elastic pair instead, e - t = g, t nu = mu, e (rho - nu) = mu */
+          double g = h[m], bq = rho * g - 2 * mu;
+          t = (-bq + sqrt(bq * bq + 4 * rho * mu * g)) / (2 * rho);
+          it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = mu / t, it->e[k * NNL + m - (ni - NNL)] = g + t;
+        }
         continue;
       }
       double t = -h[m] > o->bound_push ? -h[m] : o->bound_push;

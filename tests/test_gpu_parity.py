@@ -81,11 +81,11 @@ def test_batch_cold_and_warm_ticks(pkg, tables, oracle, gpu_lib):
         u0 = mpc.make_step(x0)
         ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (mpc.status == 0) & (ref["status"] == 0)
-        assert both.mean() > 0.9, (tick, both.mean())
+        assert both.mean() >= 0.98, (tick, both.mean())
         err = np.abs(u0 - ref["u0"])[both].max()
         assert err < 1e-5, (tick, err)  # both sides stop at KKT error 1e-8; u0 is then equal to ~1e-6
         # identical algorithm on both sides: iteration counts agree for (almost) every instance
-        assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9
+        assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() >= 0.95
         # keep both sides on the same trajectory: plant step from the oracle's control
         xn = mpc.plant_step(x0, ref["u0"])
         xo = oracle.plant_step(x0, ref["u0"])
@@ -165,7 +165,7 @@ def test_full_size_batch_properties(pkg, tables, gpu_lib):
     u0 = mpc.make_step(x0)
     st = mpc.stats()
     solved = st["status"] == 0
-    assert solved.mean() > 0.97
+    assert solved.mean() >= 0.99
     assert st["kkt"][solved].max() <= o.tol
     assert np.all(np.isfinite(u0))
     perm = np.random.default_rng(0).permutation(B)
@@ -191,13 +191,18 @@ def test_gpu_error_behaviour(pkg, tables, gpu_lib):
     x = np.tile(X0_REF, (4, 1)); x[1] = [100.0, 9.0, 0, 10, 0, 0, 0, 0]
     mpc.set_initial_guess(x)
     u0 = mpc.make_step(x)
-    assert mpc.status[1] != 0 and np.all(mpc.status[[0, 2, 3]] == 0) and np.all(np.isfinite(u0))
+    assert mpc.status[1] == 5 and np.all(mpc.status[[0, 2, 3]] == 0) and np.all(np.isfinite(u0))   # 5: locally infeasible (restoration phase)
+    assert mpc.stats()["viol"][1] > 1.0
     assert np.array_equal(u0[0], u0[2])
     with pytest.raises(pkg.LtompcError):
         pkg.BatchedMPC(tables, 1, 4)                    # horizon out of range
     o = pkg.default_options(); o.soft_rho = -1.0
     with pytest.raises(pkg.LtompcError):
         pkg.BatchedMPC(tables, 10, 4, options=o)        # the penalty of softened track constraints must be >= 0
+    o = pkg.default_options(); o.max_soc = 2
+    with pytest.raises(pkg.LtompcError):
+        pkg.BatchedMPC(tables, 10, 4, options=o)        # the second-order correction exists in the oracle only
+    o = pkg.default_options()
     # with softened track constraints the far-off-track instance is not a failure any more
     o.soft_rho = 100.0
     ms = pkg.BatchedMPC(tables, 10, 4, options=o)
@@ -225,7 +230,7 @@ def test_warm_start_options_match_oracle(pkg, tables, orc, gpu_lib):
         u0 = mpc.make_step(x0)
         ref = oracle.solve(x0, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (mpc.status == 0) & (ref["status"] == 0)
-        assert both.mean() > 0.85, (tick, both.mean())
+        assert both.mean() >= 0.95, (tick, both.mean())
         assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, tick
         if tick == 0:
             base_iters = mpc.iters[both].mean()
@@ -274,7 +279,7 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     monkeypatch.setenv("LTOMPC_RICCATI", "serial")
     u_se, s_se = run()
     ok = (s_se["status"] == 0) & (s_ref["status"] == 0)
-    assert ok.mean() > 0.9 and np.abs(u_se - u_ref)[ok].max() < 1e-6
+    assert ok.mean() >= 0.98 and np.abs(u_se - u_ref)[ok].max() < 1e-6
 
 
 def _midtrack_x0(tables, s):
@@ -321,11 +326,16 @@ def test_config_c3_batch_1024(pkg, tables, oracle, gpu_lib):
             st = mpc.stats()
             ref = oracle.solve(x[sub], N, uprev=uprev[sub], warm=ref, nthreads=16, prev_status=None if ref is None else ref["status"])
             both = (st["status"][sub] == 0) & (ref["status"] == 0)
-            assert both.mean() > 0.9, (tick, both.mean())
-            assert (st["status"][sub] == ref["status"]).mean() > 0.97, tick
+            assert both.mean() >= 0.97, (tick, both.mean())
+            assert (st["status"][sub] == ref["status"]).mean() >= 0.98, tick
             assert np.abs(u0[sub] - ref["u0"])[both].max() < 1e-5, tick
-            assert (np.abs(st["iters"][sub] - ref["iters"])[both] <= 2).mean() > 0.9, tick
-            assert (st["status"] == 0).mean() > (0.93 if tick == 0 else 0.97), (tick, np.bincount(st["status"], minlength=5))
+            assert (np.abs(st["iters"][sub] - ref["iters"])[both] <= 2).mean() >= 0.95, tick
+            # with the restoration phase 99 % and more of the batch converge on every tick (the rest: INFEASIBLE with proof)
+            assert np.isin(st["status"], (0, 1)).mean() >= 0.99, (tick, np.bincount(st["status"], minlength=6))
+            # (the cold start needs up to ~350 iterations for a handful of instances: MAX_ITER at the 300 allowed here)
+            assert np.isin(st["status"], (0, 1, 5)).mean() >= (0.995 if tick == 0 else 0.998), (tick, np.bincount(st["status"], minlength=6))
+            viol = st["viol"][st["status"] == 5]
+            assert np.all(viol > opts.tol), viol
             # both sides continue from the GPU's controls (the subset's are equal to the oracle's to 1e-5 where solved,
             # and the oracle warm-starts from its own previous iterate)
             x, uprev = mpc.plant_step(x, u0), u0
@@ -385,7 +395,7 @@ def test_latency_mode_kernels_agree(pkg, tables, oracle, gpu_lib):
     a, b, auto = run(2, 300), run(1, 300), run(0, 300)
     assert np.array_equal(auto["u0"], b["u0"])  # 24 instances: auto = latency mode
     ok = (a["status"] == 0) & (b["status"] == 0)
-    assert ok.mean() > 0.9 and np.array_equal(a["status"], b["status"])
+    assert ok.mean() >= 0.95 and np.array_equal(a["status"], b["status"])
     assert np.abs(a["u0"] - b["u0"])[ok].max() < 1e-8
     assert (np.abs(a["iters"] - b["iters"])[ok] <= 1).all()
     ref = oracle.solve(x0, N, nthreads=8)
@@ -411,24 +421,26 @@ def test_warm_reset_after_a_failed_solve(pkg, tables, orc, gpu_lib):
     multipliers and barrier; the GPU and the oracle (prev_status) do the same thing under both settings."""
     B, N = 16, 20
     x0 = pkg.sample_x0(tables, B, seed=11)
-    # a first tick that fails: an infeasible start 30 m off the track; then back on the track
-    xbad = x0.copy(); xbad[:, 1] += 30.0
+    # a first tick that fails: an infeasible start 5 m to the side (off the track); then back on the track
+    xbad = x0.copy(); xbad[:, 1] += 5.0
     res = {}
     for reset in (0, 1):
-        o = pkg.default_options(); o.max_iter, o.warm_reset_on_fail = 200, reset
-        oo = orc.default_options(); oo.max_iter, oo.warm_reset_on_fail = 200, reset
+        o = pkg.default_options(); o.max_iter, o.warm_reset_on_fail = 400, reset
+        oo = orc.default_options(); oo.max_iter, oo.warm_reset_on_fail = 400, reset
         oracle = orc.Oracle(tables.packed(), options=oo)
         mm = pkg.BatchedMPC(tables, N, B, options=o)
         mm.set_initial_guess(xbad)
         mm.make_step(xbad)
         r1 = oracle.solve(xbad, N, nthreads=8)
-        assert (mm.status != 0).mean() > 0.8 and np.array_equal(mm.status != 0, r1["status"] != 0)
+        # (locally infeasible problems: INFEASIBLE after 100 - 200 iterations, a few at the iteration limit on one side only)
+        assert (mm.status != 0).mean() > 0.8 and np.array_equal(mm.status != 0, r1["status"] != 0) and (mm.status == r1["status"]).mean() >= 0.75
         u2 = mm.make_step(x0)   # back on the track: warm start from the failed solve
         r2 = oracle.solve(x0, N, uprev=r1["u0"], warm=r1, nthreads=8, prev_status=r1["status"])
         both = (mm.status == 0) & (r2["status"] == 0)
-        assert both.mean() > 0.6, (reset, both.mean())
+        assert both.mean() >= 0.9, (reset, both.mean())
+        assert (mm.status == r2["status"]).mean() >= 0.9
         assert np.abs(u2 - r2["u0"])[both].max() < 1e-5
-        assert (np.abs(mm.iters - r2["iters"])[both] <= 2).mean() > 0.8
+        assert (np.abs(mm.iters - r2["iters"])[both] <= 2).mean() >= 0.85
         res[reset] = (mm.iters.copy(), mm.status.copy())
         mm.close()
     # the reset is not a no-op: iteration counts differ between the two policies
@@ -477,9 +489,9 @@ def test_soft_track_constraints_match_oracle(pkg, tables, orc, gpu_lib):
             u0 = mpc.make_step(x)
             ref = oracle.solve(x, N, uprev=uprev, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
             both = (mpc.status == 0) & (ref["status"] == 0)
-            assert both.mean() > 0.9, (mode, tick, both.mean())
+            assert both.mean() >= 0.95, (mode, tick, both.mean())
             assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, (mode, tick)
-            assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9, (mode, tick)
+            assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() >= 0.95, (mode, tick)
             assert np.abs(mpc.stats()["obj"] - ref["obj"])[both].max() < 1e-6 * max(1.0, np.abs(ref["obj"][both]).max())
             x, uprev = oracle.plant_step(x, ref["u0"]), ref["u0"]
         mpc.close()
@@ -528,9 +540,9 @@ def test_other_bound_patterns_use_the_generic_kernels(pkg, tables, orc, gpu_lib)
         for x, ref in ((x0, r1), (x1, r2)):
             u0 = mpc.make_step(x)
             both = (mpc.status == 0) & (ref["status"] == 0)
-            assert both.mean() > 0.85, (mode, both.mean())
+            assert both.mean() >= 0.95, (mode, both.mean())
             assert np.abs(u0 - ref["u0"])[both].max() < 1e-5, mode
-            assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() > 0.9, mode
+            assert (np.abs(mpc.iters - ref["iters"])[both] <= 2).mean() >= 0.95, mode
         mpc.close()
 
 
@@ -551,7 +563,7 @@ def test_periodic_tables_across_the_seam_and_for_more_than_a_lap(pkg, tables, or
     u0 = mpc.make_step(x0)
     ref = oracle.solve(x0, N, nthreads=8)
     both = (mpc.status == 0) & (ref["status"] == 0)
-    assert both.mean() > 0.9 and np.abs(u0 - ref["u0"])[both].max() < 1e-5
+    assert both.mean() >= 0.95 and np.abs(u0 - ref["u0"])[both].max() < 1e-5
     ok = both[:8] & both[8:16]
     assert ok.sum() >= 6 and np.abs(u0[:8] - u0[8:16])[ok].max() < 1e-7  # one lap further on: the same control
     X, _ = mpc.prediction()
@@ -601,3 +613,150 @@ def test_packed_order_is_kept_between_ticks_and_invisible(pkg, tables, gpu_lib):
     assert np.array_equal(Xa, Xb) and np.array_equal(Ua, Ub)
     assert max(h[2] for h in a.history()) == B and min(h[2] for h in a.history()) < B // 2  # (the solve did re-pack)
     a.close(); b.close()
+
+
+STALL_STATES = {   # tests/test_oracle_nlp.py: closed-loop states at which the round-1 solver (no restoration phase) stalled
+    20: ([226.623754, -0.545036120, -0.0112268024, 8.52329373, 0.122918012, 0.161888169, 0.0837443810, 0.371730909], [0.78837973, -0.00572868]),
+    40: ([271.551631, -3.15996996e-03, -0.138116402, 9.84560464, 0.483360380, 0.717172238, 0.338696158, -0.336634617], [1.17640462, -0.99999992]),
+}
+
+
+@pytest.mark.parametrize("mode", [2, 1])
+def test_restoration_phase_matches_oracle(pkg, tables, orc, oracle, gpu_lib, mode):
+    """VERDICT r1 item 1.  The N = 20 stall state (a FEASIBLE NLP on which the filter line search fails) converges with
+    hard constraints through the restoration phase; the N = 40 one ends INFEASIBLE with the violation as proof; both as
+    on the oracle (status, restoration count, iteration count, control, violation), in both evaluation-kernel modes.
+    Cold start and u_prev = 0 on both sides (the C ABI has no entry point that sets u_prev)."""
+    import nlp_reference as R
+    o = pkg.default_options(); o.latency_mode = mode
+    for N, want in ((20, 0), (40, 5)):
+        x = np.array([STALL_STATES[N][0]])
+        m = pkg.BatchedMPC(tables, N, 1, options=o)
+        m.set_initial_guess(x)
+        u = m.make_step(x)
+        s = m.stats()
+        r = oracle.solve(x, N)
+        assert s["status"][0] == want == r["status"][0] and s["n_resto"][0] == 1 == r["n_resto"][0], (N, s, r["status"])
+        assert abs(int(s["iters"][0]) - int(r["iters"][0])) <= 2 and np.abs(u - r["u0"]).max() < 1e-6
+        if want == 0:
+            assert s["viol"][0] == 0.0 and s["kkt"][0] <= o.tol
+            k = R.kkt_residuals(m.iterate(), x[0], np.zeros(2), tables, o.smooth_eps_min, 0)   # a KKT point of the HARD problem
+            assert k["stationarity"] < 1e-6 and k["equality"] < 1e-7 and k["ineq_violation"] < 1e-7 and k["complementarity"] < 1e-7, k
+        else:
+            assert s["viol"][0] > 1e-5 and s["viol"][0] == pytest.approx(r["viol"][0], rel=1e-3)
+        m.close()
+    # without the restoration phase (options.resto_rho = 0: round-1 behaviour) the same solve ends STALLED
+    o.resto_rho = 0.0
+    m = pkg.BatchedMPC(tables, 20, 1, options=o)
+    x = np.array([STALL_STATES[20][0]])
+    m.set_initial_guess(x); m.make_step(x)
+    assert m.status[0] == 4
+    m.close()
+
+
+def test_reference_loop_500_ticks_hard_constraints(pkg, tables, gpu_lib):
+    """The reference's closed loop as written (src/mpc.py:104-153): N = 10, x0 = [0,0,0,5,0,0,0,0.1], 500 ticks, hard track
+    constraints, through the mirrored classes with the reference's call sequence.  Every tick ends SOLVED / ACCEPTABLE, or
+    INFEASIBLE with the proof IPOPT's restoration phase would give: a stationary point of the violation with violation > tol.
+    (Round 1: the loop stopped converging at s = 227 m and no later tick recovered.)"""
+    track = pkg.Track("MX-5", "buckmore", "curvature", 846)                  # mpc.py:89
+    model = pkg.VehicleModel(None, track)                                     # mpc.py:99
+    controller = pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)))    # mpc.py:104
+    x0 = np.reshape([0, 0, 0, 5.0, 0, 0, 0, 0.1], (-1, 1))                  # mpc.py:107-110
+    sim = pkg.Simulator(model).simulator                                      # mpc.py:114 (the reference passes the model)
+    sim.x0 = x0
+    controller.mpc.x0 = x0
+    controller.mpc.set_initial_guess()                                        # mpc.py:117-118
+    hist, proofs = {}, []
+    for i in range(500):                                                      # mpc.py:125,140
+        u0 = controller.mpc.make_step(x0)                                     # mpc.py:142
+        st = int(controller.mpc.solver_stats["status"][0])
+        hist[st] = hist.get(st, 0) + 1
+        if st == 5:
+            proofs.append(float(controller.solver.stats()["viol"][0]))
+        assert st in (0, 1, 5), (i, st)
+        y = sim.make_step(u0)                                                 # mpc.py:143
+        x0 = y                                                                # StateFeedback (mpc.py:144)
+    assert all(v > 1e-8 for v in proofs), proofs
+    assert hist.get(0, 0) + hist.get(1, 0) >= 490 and float(x0[0, 0]) > 480.0, (hist, x0[0, 0])
+    controller.solver.close()
+
+
+def test_config_c5_full_lap_n60_hard_constraints(pkg, tables, gpu_lib):
+    """BASELINE config 5 as stated: closed loop from the reference's x0, horizon N = 60, the reference's HARD track
+    constraints, until the horizon reaches the end of the tables (one lap minus the look-ahead).  Every tick converges or
+    ends INFEASIBLE with a violation as proof (5 of ~720 ticks, millimetres: cars entering two corners a little too fast)."""
+    o = pkg.default_options()
+    x, N = X0_REF.copy(), 60
+    mpc = pkg.BatchedMPC(tables, N, 1, options=o)
+    mpc.set_initial_guess(x)
+    s_end = tables.s_max - 0.1 * N * 25.0
+    ticks, hist, worst, viols = 0, {}, 0.0, []
+    while x[0, 0] < s_end and ticks < 1000:
+        u = mpc.make_step(x)
+        st = int(mpc.status[0]); hist[st] = hist.get(st, 0) + 1
+        assert st in (0, 1, 5), (ticks, x[0, 0], st)
+        if st == 5:
+            viols.append(float(mpc.stats()["viol"][0]))
+        x = mpc.plant_step(x, u, 100); ticks += 1
+        nl, nr = np.interp(x[0, 0], tables.s_arc, tables.n_left), np.interp(x[0, 0], tables.s_arc, tables.n_right)
+        sa, cw = 1.5 * abs(np.sin(x[0, 2])), 1.15 * np.cos(x[0, 2])  # the reference's constraints, model.py:70-84
+        worst = max(worst, x[0, 1] - sa + cw - nl, -x[0, 1] + sa + cw - nr)
+    assert x[0, 0] >= s_end and 650 < ticks < 800, (ticks, x[0, 0])
+    assert hist.get(5, 0) <= 12 and all(1e-8 < v < 0.05 for v in viols), (hist, viols)
+    assert worst < 0.05, worst
+    mpc.close()
+
+
+def test_poisoned_work_buffers_give_identical_results(pkg, tables, gpu_lib, monkeypatch):
+    """every device work array is zero-filled at creation, which would hide a read of a word that no
+    kernel has written.  LTOMPC_POISON=1 fills them with NaN bit patterns instead: results must be bit-identical, on the
+    narrow-launch path, on the wide path with re-packing, with soft constraints (elastic planes) and in latency mode."""
+    cases = [(300, 20, {}), (1500, 10, {}), (64, 20, {"soft_rho": 100.0}), (40, 12, {"latency_mode": 1}), (3, 2, {})]
+    for B, N, opts in cases:
+        x0 = pkg.sample_x0(tables, B, seed=31)
+        x0[0] = STALL_STATES[20][0]   # (one instance that goes through the restoration phase)
+        out = []
+        for poison in ("0", "1"):
+            monkeypatch.setenv("LTOMPC_POISON", poison)
+            o = pkg.default_options()
+            for k, v in opts.items():
+                setattr(o, k, v)
+            m = pkg.BatchedMPC(tables, N, B, options=o)
+            m.set_initial_guess(x0)
+            u1 = m.make_step(x0)
+            x1 = m.plant_step(x0, u1, 50)
+            u2 = m.make_step(x1)
+            s = m.stats(); X, U = m.prediction(); it = m.iterate()
+            out.append((u1, u2, s["status"], s["iters"], s["kkt"], s["obj"], X, U, it["L1"], it["T"], it["NU"]))
+            m.close()
+        for a, b in zip(*out):
+            assert np.array_equal(a, b, equal_nan=False), (B, N, opts)
+        assert np.all(np.isfinite(out[1][0])) and np.all(np.isfinite(out[1][6]))
+    monkeypatch.delenv("LTOMPC_POISON")
+
+
+def test_exact_piecewise_linear_tables_on_gpu(pkg, tables, orc, gpu_lib):
+    """smooth_eps_min = smooth_scale = 0: the reference's exact piece-wise-linear tables (no rounding of the knots), the
+    HIP path against the oracle on a small batch, and against the default (1e-4 m rounding) where both converge."""
+    B, N = 24, 20
+    x0 = np.vstack([X0_REF, pkg.sample_x0(tables, B - 1, seed=41)])
+    o = pkg.default_options(); o.smooth_eps_min, o.smooth_scale = 0.0, 0.0
+    oo = orc.default_options(); oo.smooth_eps_min, oo.smooth_scale = 0.0, 0.0
+    ref = orc.Oracle(tables.packed(), options=oo).solve(x0, N, nthreads=8)
+    for mode in (2, 1):
+        o.latency_mode = mode
+        m = pkg.BatchedMPC(tables, N, B, options=o)
+        m.set_initial_guess(x0)
+        u = m.make_step(x0)
+        both = (m.status == 0) & (ref["status"] == 0)
+        assert both.mean() >= 0.8 and both[0], (mode, both.mean(), m.status, ref["status"])
+        assert np.abs(u - ref["u0"])[both].max() < 1e-5, mode
+        assert np.array_equal(np.isin(m.status, (0, 1)), np.isin(ref["status"], (0, 1))) or (m.status == ref["status"]).mean() >= 0.9
+        m.close()
+    d = pkg.BatchedMPC(tables, N, B)
+    d.set_initial_guess(x0)
+    ud = d.make_step(x0)
+    ok = (d.status == 0) & (ref["status"] == 0)
+    assert np.abs(ud - ref["u0"])[ok].max() < 1e-5   # the rounding moves the solution by less than the solve tolerance shows
+    d.close()

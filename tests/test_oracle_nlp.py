@@ -101,8 +101,8 @@ def test_solver_failure_is_a_status_not_an_error(oracle):
     """Like the reference (IPOPT failure is silent): an infeasible start returns the last iterate + status."""
     x_bad = np.array([[100.0, 9.0, 0.0, 10.0, 0, 0, 0, 0]])  # 9 m off the race line: outside the track
     r = oracle.solve(x_bad, 10)
-    assert r["status"][0] != 0 and np.all(np.isfinite(r["u0"]))
-    assert r["iters"][0] < oracle.o.max_iter  # stall detection, not the iteration limit
+    assert r["status"][0] == 5 and np.all(np.isfinite(r["u0"]))   # INFEASIBLE: the restoration phase cannot remove the violation
+    assert r["viol"][0] > 1.0 and r["iters"][0] < oracle.o.max_iter
 
 
 def test_edge_horizons(oracle):
@@ -147,12 +147,14 @@ STALL_STATES = {
 
 @pytest.mark.parametrize("N", [20, 40])
 def test_soft_track_constraints_solve_where_the_hard_solve_stalls(orc, tables, N):
-    """The states at which the closed loop with the reference's hard track constraints stops converging (no
-    restoration phase here).  The softened NLP converges from them, to a point that satisfies its KKT
-    conditions as evaluated by the independent torch implementation: for N = 20 without any violation (a KKT point of
-    the hard NLP, multipliers 4 << rho: the stall was the solver's), for N = 40 with 0.1 mm of overlap at nu = rho."""
+    """The states at which the closed loop with the reference's hard track constraints stopped converging in round 1
+    (filter line search without a restoration phase: options.resto_rho = 0).  The softened NLP converges from them, to a
+    point that satisfies its KKT conditions as evaluated by the independent torch implementation: for N = 20 without any
+    violation (a KKT point of the hard NLP, multipliers 4 << rho: the stall was the solver's), for N = 40 with 0.1 mm of
+    overlap at nu = rho."""
     x, up = (np.array([v]) for v in STALL_STATES[N])
-    assert orc.Oracle(tables.packed()).solve(x, N, up)["status"][0] == 4
+    o0 = orc.default_options(); o0.resto_rho = 0.0
+    assert orc.Oracle(tables.packed(), options=o0).solve(x, N, up)["status"][0] == 4
     rho = 100.0
     o = orc.default_options(); o.soft_rho = rho
     soft = orc.Oracle(tables.packed(), options=o)
@@ -164,6 +166,71 @@ def test_soft_track_constraints_solve_where_the_hard_solve_stalls(orc, tables, N
     assert k["soft_violation"] < 1e-3, k
     assert (k["soft_violation"] == 0.0) == (N == 20)
     assert k["objective"] == pytest.approx(r["obj"][0], rel=1e-8, abs=1e-6)
+
+
+def test_restoration_phase_solves_the_feasible_stall_state(orc, oracle, tables):
+    """the N = 20 stall state is a FEASIBLE NLP on which the line search fails (the iterate jams
+    against the steering-rate bound).  With the restoration phase (elastic mode, options.resto_rho = 1000, the default)
+    the hard-constrained solve converges: status SOLVED on the hard problem's own KKT error, a KKT point by the
+    independent torch evaluation, equal to what the softened NLP finds."""
+    x, up = (np.array([v]) for v in STALL_STATES[20])
+    r = oracle.solve(x, 20, up)
+    assert r["status"][0] == 0 and r["n_resto"][0] == 1 and r["viol"][0] == 0.0 and r["kkt"][0] <= 1e-8
+    k = R.kkt_residuals(r, x[0], up[0], tables, oracle.o.smooth_eps_min, 0)
+    assert k["stationarity"] < 1e-6 and k["equality"] < 1e-7 and k["ineq_violation"] < 1e-7, k
+    assert k["complementarity"] < 1e-7 and k["min_multiplier"] >= 0.0, k
+    o = orc.default_options(); o.soft_rho = 100.0
+    soft = orc.Oracle(tables.packed(), options=o).solve(x, 20, up)
+    assert np.abs(r["u0"] - soft["u0"]).max() < 1e-6 and np.abs(r["X"] - soft["X"]).max() < 1e-5
+    # ... also from a cold start and u_prev = 0 (the case traced in DESIGN.md §3)
+    r0 = oracle.solve(x, 20)
+    assert r0["status"][0] == 0 and r0["n_resto"][0] == 1 and r0["iters"][0] < 40
+
+
+def test_restoration_phase_reports_local_infeasibility(orc, oracle, tables):
+    """The N = 40 stall state: the horizon problem is (marginally) infeasible.  The restoration phase converges to a
+    stationary point of the violation with 0.1 mm of overlap left: status INFEASIBLE (IPOPT: 'converged to a point of
+    local infeasibility'), the same overlap for a 100 times larger penalty, and the iterate returned satisfies the KKT
+    conditions of the elastic problem (torch)."""
+    x, up = (np.array([v]) for v in STALL_STATES[40])
+    r = oracle.solve(x, 40, up)
+    assert r["status"][0] == 5 and r["n_resto"][0] == 1 and 1e-5 < r["viol"][0] < 1e-3
+    o = orc.default_options(); o.resto_rho = 1e5
+    r5 = orc.Oracle(tables.packed(), options=o).solve(x, 40, up)
+    assert r5["status"][0] == 5 and r5["viol"][0] == pytest.approx(r["viol"][0], rel=0.1)
+    k = R.kkt_residuals(r, x[0], up[0], tables, oracle.o.smooth_eps_min, 0, rho=oracle.o.resto_rho)
+    assert k["stationarity"] < 1e-5 and k["equality"] < 1e-7 and k["ineq_violation"] < 1e-7, k
+    assert k["max_track_multiplier"] <= oracle.o.resto_rho and k["soft_violation"] == pytest.approx(r["viol"][0], rel=1e-3), k
+
+
+def test_reference_loop_runs_with_hard_constraints(oracle, tables):
+    """The reference's loop (src/mpc.py:104-153: N = 10, x0 = [0,0,0,5,0,0,0,0.1], 500 ticks, hard track constraints):
+    every tick ends SOLVED / ACCEPTABLE, or INFEASIBLE with a proof (the elastic problem's stationary point keeps a
+    violation > tol).  In round 1 the loop stopped converging at s = 227 m and never recovered."""
+    x, warm, st, up = np.array([[0, 0, 0, 5, 0, 0, 0, 0.1]], float), None, None, np.zeros((1, 2))
+    hist = {}
+    for tick in range(500):
+        r = oracle.solve(x, 10, up, warm, prev_status=st)
+        warm, st, up = r, r["status"], r["u0"]
+        s = int(st[0]); hist[s] = hist.get(s, 0) + 1
+        assert s in (0, 1) or (s == 5 and r["viol"][0] > 1e-8), (tick, s, r["viol"][0])
+        x = oracle.plant_step(x, r["u0"], n_sub=100)
+    assert hist.get(0, 0) + hist.get(1, 0) >= 490 and x[0, 0] > 480.0, (hist, x[0, 0])
+
+
+def test_second_order_correction_in_the_oracle(orc, pkg, tables):
+    """options.max_soc (IPOPT's second-order correction; oracle only): corrected steps are taken (n_soc > 0), the solves
+    end at the same KKT points, and - the reason the kernels do not have it - the iteration counts do not improve."""
+    x0 = pkg.sample_x0(tables, 96, seed=4)
+    o = orc.default_options(); o.max_soc = 4
+    a = orc.Oracle(tables.packed()).solve(x0, 40, nthreads=8)
+    b = orc.Oracle(tables.packed(), options=o).solve(x0, 40, nthreads=8)
+    assert a["n_soc"].sum() == 0 and b["n_soc"].sum() >= 10
+    ok = (a["status"] == 0) & (b["status"] == 0)
+    assert ok.mean() > 0.95
+    same = np.abs(a["u0"] - b["u0"]).max(axis=1)[ok] < 1e-6
+    assert same.mean() > 0.9
+    assert b["iters"][ok].sum() > 0.9 * a["iters"][ok].sum()
 
 
 def test_periodic_tables_option(orc, tables):
