@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — MPC solves/s of the batched make_step path on N MI355X (one process per GPU).
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W     (N > 1 via torch.distributed.run)
-One "step" = one control tick of the reference's closed loop (src/mpc.py:140-153) for every instance of the
-batch: make_step (one NLP solve per instance, warm-started from the previous solution) followed by the plant
-step that produces the next x0.  Inputs are resident in HBM when the timed region starts.
-Workload: BASELINE.json's metric config — horizon N=40, 8192 instances per GPU sampled along buckmore
-(SURVEY.md §8d C3/C4), weak scaling (per-GPU batch fixed; instances are independent, no data-path collective).
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N = 1: this process is the one rank.  N > 1 and no RANK in the environment: this process starts
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...` as a CHILD (before
+  anything touches the GPU) and relays rank 0's JSON line; under torchrun (RANK set) it is one of the N ranks.
+One "step" = one control tick of the reference's closed loop (src/mpc.py:140-153) for every instance of the batch:
+make_step (one NLP solve per instance, warm-started from the previous solution, the reference's solver settings incl.
+max_iter = 1000) followed by the plant step that produces the next x0.  Inputs are resident in HBM when the timed region starts.
+Workload: BASELINE.json's metric config — horizon N = 40, 8192 instances per GPU sampled along buckmore (SURVEY.md §8d
+C3/C4), weak scaling (per-GPU batch fixed; instances are independent NLPs, no data-path collective).
+`value` counts CONVERGED solves only (status SOLVED / ACCEPTABLE); `solves_attempted_per_s` has every instance.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -14,6 +18,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,43 +38,117 @@ BYTES_PER_STAGE_ITER = 8 * (2 * WORDS_QP + WORDS_RIC_OUT + WORDS_EVAL_IN)  # 310
 BYTES_BY_KERNEL = {  # share of the 3104 B each kernel class moves (algorithmic, not measured traffic)
     "eval": 8 * (WORDS_QP + WORDS_EVAL_IN), "riccati": 8 * (WORDS_QP + WORDS_RIC_OUT),
     "expand": 8 * (WORDS_EVAL_IN + WORDS_RIC_OUT), "linesearch": 8 * WORDS_EVAL_IN, "pick": 0, "update": 8 * 2 * WORDS_EVAL_IN,
-    "riccati1": 0,  # one-wavefront-per-instance sweep of the narrow launches: latency-bound by construction, no roofline claim
-    "step1": 0,     # fused line-search / pick / update kernel of the narrow launches: likewise
+    "riccati1": 8 * (WORDS_QP + WORDS_RIC_OUT),  # the one-wavefront-per-instance sweep of the narrow launches: same words as "riccati"
+    "step1": 8 * (WORDS_EVAL_IN + 2 * WORDS_EVAL_IN),  # fused line search + pick + update of the narrow launches: their words together
 }
+KERNEL_OF_CLASS = {"eval": "k_eval", "riccati": "k_riccati8", "expand": "k_expand", "linesearch": "k_linesearch", "pick": "k_pick",
+                   "update": "k_update", "riccati1": "k_riccati1", "step1": "k_step1"}
+STATUS_NAMES = ("solved", "acceptable", "max_iter", "numerical", "stalled", "infeasible", "6", "other")
 
 
 def load_pmc_traffic(kernel, B, N):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this same command (separate rocprofv3 --pmc
     passes, profiles/pmc_traffic.py); None when there is none for this batch / horizon."""
     import glob
-    import json as _json
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_traffic.json")), reverse=True):
         try:
-            d = _json.load(open(f))
+            d = json.load(open(f))
         except Exception:
             continue
-        k = d.get("kernels", {}).get("k_" + kernel)
+        k = d.get("kernels", {}).get(kernel)
         if k and d.get("batch") == B and d.get("horizon") == N:
             return dict(k, source=os.path.relpath(f, ROOT))
     return None
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
-    ap.add_argument("--max-iter", type=int, default=150, help="interior-point iteration budget per solve")
+    ap.add_argument("--max-iter", type=int, default=1000, help="interior-point iteration budget per solve (reference: ipopt.max_iter = 1000, controller.py:18)")
     ap.add_argument("--soft-rho", type=float, default=0.0, help="options.soft_rho for the timed run and the CPU baseline (extension: "
                     "softened track constraints; 0 = the reference's hard constraints)")
     ap.add_argument("--poll-every", type=int, default=4, help="iterations between two read-backs of the number of unfinished instances")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="instances solved by the CPU oracle for cpu_baseline")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="instances solved by the CPU oracle for cpu_baseline (0: sized for ~10 s on the host's cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements after the timed region (batch 1, N = 60, tuned warm start)")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra measurements after the timed region (batch 1, N = 60, max_iter 150, tuned warm start)")
+    ap.add_argument("--selftest-stub", action="store_true", help="CPU-only plumbing test of the multi-rank path (tests/test_distributed_cpu.py): gloo "
+                    "instead of RCCL and a stand-in for the solver; the line it prints says data = stub and is not a measurement")
+    return ap.parse_args(argv)
+
+
+def launch_ranks(args) -> int:
+    """--gpus N > 1 outside torchrun: start the N ranks as a child process group and pass rank 0's JSON line through.
+    Nothing in this process has touched the GPU (no torch.cuda / HIP call): it only waits for the child."""
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:  # relay: the last JSON object line rank 0 printed is the result
+        out = out.rstrip("\n")
+        if out.startswith("{") and out.endswith("}"):
+            line = out
+        else:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        n = json.loads(line).get("n_gpus")
+        if n != args.gpus:
+            print(f"bench.py: asked for {args.gpus} ranks, the result reports {n}", file=sys.stderr)
+            rc = rc or 1
+        print(line)
+    return rc if rc or line is not None else 1
+
+
+def stub_main(args):
+    """Plumbing test of the multi-rank path without a GPU (never a measurement): the same launcher, rendezvous, barrier,
+    max-over-ranks timing and sum-over-ranks aggregation as the real run, with gloo and a stand-in for the solver."""
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    shard = import_module("lap-time-optimization_amd.sharding")
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = args.batch
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    converged = 0
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))  # ranks differ: the slowest one sets the time
+        converged += B - rank  # rank r "fails" r instances per tick
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    _, _, elapsed_max = shard.reduce_stats(0, 0, elapsed)
+    tot = torch.tensor([float(converged)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        print(json.dumps({"metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": float(tot.item()) / elapsed_max, "unit": "MPC solves/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
+                          "config": {"workload": "plumbing self-test, no solver", "batch_per_gpu": B}, "converged_solves": float(tot.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+    if args.selftest_stub:
+        return stub_main(args)
 
     import torch
     import ltompc
@@ -77,6 +156,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -112,9 +193,9 @@ def main():
             dist.barrier(device_ids=[local_rank])
 
     # ---- warm-up: cold start (do_mpc set_initial_guess) + W ticks, untimed.  Every launch is bracketed by HIP events
-    #      in the last of them: which kernel class takes the most device time (the one the roofline is quoted for) and the per-class
-    #      totals come from these ticks; the timed ticks bracket the launches of that class only (two events per
-    #      iteration instead of seven: the full bracketing costs 4 % of the throughput at this speed, one class 1 %).
+    #      in the last of them: which kernel class takes the most device time (the one the roofline is quoted for; all 8
+    #      classes compete) and the per-class totals come from that tick; the timed ticks bracket the launches of that class
+    #      only (two events per iteration instead of seven: the full bracketing costs 4 % of the throughput, one class 1 %).
     mpc.set_initial_guess_dev(x.data_ptr())
     for w in range(args.warmup):
         if w == args.warmup - 1:
@@ -122,86 +203,107 @@ def main():
         tick()
     torch.cuda.synchronize(dev)
     tm_warm = mpc.timing() if (not args.no_profile and args.warmup > 0) else None
-    dom = None
-    if tm_warm is not None:
-        dom = max((k for k in tm_warm["ms"] if BYTES_BY_KERNEL[k] > 0), key=lambda k: tm_warm["ms"][k])  # dominant wide (HBM-streaming) kernel
+    dom = max(tm_warm["ms"], key=lambda k: tm_warm["ms"][k]) if tm_warm is not None else None
 
-    # ---- timed region: exactly K ticks
+    # ---- timed region: exactly K ticks.  After every tick: the device-side histogram of the statuses (one tiny kernel
+    #      and a 72-byte copy, inside the timed region) and, when profiling, the per-iteration counts of unfinished instances.
     mpc.set_profiling(not args.no_profile, only=dom)
-    iters_sum, solved, ip_launch_iters = 0, 0, 0
+    per_tick_iters, per_tick_counts, per_tick_itersum, active_hist = [], [], [], []
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    per_tick = []
     for _ in range(args.steps):
         tick()
-        per_tick.append(mpc.timing()["ip_iterations"])
+        c, isum = mpc.status_counts()
+        per_tick_counts.append(c), per_tick_itersum.append(isum)
+        per_tick_iters.append(mpc.timing()["ip_iterations"])
+        if not args.no_profile:
+            active_hist.append(mpc.active_history())
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    st = mpc.stats()  # last tick
     tm = mpc.timing()
-    log = mpc.launch_log() if not args.no_profile else None
+    log = mpc.launch_log(with_iterations=True) if not args.no_profile else None
     mpc.set_profiling(False)
 
+    counts = np.array(per_tick_counts, dtype=np.float64)  # (K, 8)
+    itersum = np.array(per_tick_itersum, dtype=np.float64)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([float((st["status"] == 0).sum()), float(st["iters"].sum())], dtype=torch.float64, device=dev)
+        agg = torch.from_numpy(np.concatenate([counts.ravel(), itersum])).to(dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        n_solved_last, iters_last = agg.tolist()
-    else:
-        n_solved_last, iters_last = float((st["status"] == 0).sum()), float(st["iters"].sum())
+        agg = agg.cpu().numpy()
+        counts, itersum = agg[:counts.size].reshape(counts.shape), agg[counts.size:]
+    n_all = B * world
+    converged_per_tick = counts[:, 0] + counts[:, 1]
+    value = float(converged_per_tick.sum()) / elapsed
+    attempted = n_all * args.steps / elapsed
 
-    total_solves = B * world * args.steps
-    value = total_solves / elapsed
-
-    # ---- roofline of the dominant kernel (rank 0; HIP events on the launch stream, accumulated over the timed ticks)
+    # ---- roofline (rank 0; HIP events on the launch stream, accumulated over the timed ticks)
     roofline = None
     if not args.no_profile and rank == 0:
         ms, ln = tm["ms"], tm["launches_by_kernel"]
+        names = list(ms.keys())
         if dom is None:  # no warm-up ticks: every launch of the timed region was bracketed
-            dom = max((k for k in ms if BYTES_BY_KERNEL[k] > 0), key=lambda k: ms[k])
-        avg_ms = ms[dom] / max(1, ln[dom])
-        # instances still iterating, averaged over launches (finished instances idle inside a launch)
-        active_per_launch = float(st["iters"].sum()) * args.steps / max(1, sum(per_tick))  # last tick's distribution
-        bytes_per_launch = active_per_launch * N * BYTES_BY_KERNEL[dom]
+            dom = max(ms, key=lambda k: ms[k])
+        kind, width, lms, lit = log
+        # unfinished instances a launch of iteration `it` of tick `tk` works on: those that passed the previous
+        # iteration's termination test (all B in iteration 0), at most the launch width
+        tick_of_launch = np.zeros(kind.size, dtype=np.int64)
+        tk = 0
+        for i in range(1, kind.size):
+            if lit[i] < lit[i - 1]:
+                tk += 1
+            tick_of_launch[i] = tk
+        def active_in(tk, it):
+            a = active_hist[min(tk, len(active_hist) - 1)]
+            return B if it == 0 else (int(a[it - 1]) if it - 1 < len(a) else 0)
+        sel = kind == names.index(dom)
+        act = np.array([min(active_in(int(tick_of_launch[i]), int(lit[i])), int(width[i])) for i in np.where(sel)[0]], dtype=np.float64)
+        avg_ms = float(lms[sel].mean())
+        bytes_per_launch = float(act.mean()) * N * BYTES_BY_KERNEL[dom]
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_" + dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_launch": bytes_per_launch,
+        roofline = {"bound": "hbm", "kernel": KERNEL_OF_CLASS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms, "launches_timed": int(sel.sum()),
+                    "active_instances_per_launch": float(act.mean()), "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "algorithmic_bytes_per_instance_interval": BYTES_BY_KERNEL[dom],
                     "kernel_ms_total": {k: round(v, 3) for k, v in (tm_warm or tm)["ms"].items()},
                     "launches": (tm_warm or tm)["launches_by_kernel"],
                     "kernel_ms_total_from": ("the last warm-up tick, every launch bracketed"
                                              if tm_warm else "the timed ticks, every launch bracketed"),
-                    "timed_region_events": ("launches of k_" + dom + " only") if tm_warm else "every launch"}
-        # the same kernel over its full-width launches only (every instance of the batch still iterating or idle in
-        # its wavefront; the launches after the first re-packing are sized for a few stragglers and latency-bound)
-        pmc = load_pmc_traffic(dom, B, N)
+                    "timed_region_events": ("launches of " + KERNEL_OF_CLASS[dom] + " only") if tm_warm else "every launch"}
+        pmc = load_pmc_traffic(KERNEL_OF_CLASS[dom], B, N)
         if pmc:
-            roofline["traffic"] = pmc["traffic_avg_all_launches"]
+            roofline["traffic"] = pmc.get("traffic_avg_all_launches")
             roofline["traffic_source"] = pmc["source"]
-        names = list(ms.keys())
-        kind, width, lms = log
-        full = (kind == names.index(dom)) & (width == B)
+        # the whole tick against the same roof: every (instance, interval, iteration) moves 3104 algorithmic bytes
+        inst_iters = float(np.mean([B + float(a[:max(0, n - 1)].sum()) for a, n in zip(active_hist, per_tick_iters)]))
+        tick_bytes = inst_iters * N * BYTES_PER_STAGE_ITER
+        ms_per_step = 1e3 * elapsed / args.steps
+        roofline["tick"] = {"algorithmic_bytes_per_tick": tick_bytes, "instance_iterations_per_tick": inst_iters, "ms_per_step": ms_per_step,
+                            "achieved": tick_bytes / (ms_per_step * 1e-3) / 1e9, "frac": tick_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # the widest launches of the dominant class (every instance of the batch still iterating or idle in its wavefront)
+        full = sel & (width == B)
         if full.any():
             fw_ms = float(lms[full].mean())
             fw_bytes = B * N * BYTES_BY_KERNEL[dom]
             roofline["full_width"] = {"launches": int(full.sum()), "avg_launch_ms": fw_ms, "algorithmic_bytes_per_launch": fw_bytes,
                                       "achieved": fw_bytes / (fw_ms * 1e-3) / 1e9, "frac": fw_bytes / (fw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            by_width = {}
-            for w in sorted(set(int(x) for x in width[kind == names.index(dom)]), reverse=True)[:12]:
-                sel = (kind == names.index(dom)) & (width == w)
-                by_width[str(w)] = [int(sel.sum()), round(float(lms[sel].mean()), 4)]
-            roofline["avg_launch_ms_by_width"] = by_width  # width -> [launches, avg ms]
             if pmc:
-                roofline["full_width"]["traffic"] = pmc["traffic"]
+                roofline["full_width"]["traffic"] = pmc.get("traffic")
+        by_width = {}
+        for w in sorted(set(int(v) for v in width[sel]), reverse=True)[:12]:
+            s2 = sel & (width == w)
+            by_width[str(w)] = [int(s2.sum()), round(float(lms[s2].mean()), 4)]
+        roofline["avg_launch_ms_by_width"] = by_width  # width -> [launches, avg ms]
 
-    # ---- batch = 1 latency (second handle, same stream), reported as an extra
+    # ---- extras (rank 0, after the timed region)
     extras = {}
     if rank == 0 and not args.no_extras:
+        # batch = 1 latency (second handle, same stream)
         m1 = ltompc.BatchedMPC(tables, n_horizon=N, batch=1, options=opts, device=local_rank)
         m1.set_stream(stream.cuda_stream)
         x1 = ltompc.X0_REFERENCE[None].copy()
@@ -219,108 +321,100 @@ def main():
         extras["batch1_ms_per_solve"] = 1e3 * t_solve / nb
         extras["batch1_iters_last"] = int(m1.iters[0])
         m1.close()
-        # BASELINE config 5 (closed loop from the reference's x0, horizon N = 60): real-time factor over the first 300
-        # ticks (30 s of driving, s = 0 .. ~290 m; the formulation does not get through the narrowest section of the
-        # track at s ~ 416 m, so a whole lap is not a meaningful workload)
+        # BASELINE config 5: closed loop from the reference's x0, horizon N = 60, the reference's hard track constraints,
+        # until the horizon reaches the end of the tables (one lap minus the look-ahead)
         o60 = ltompc.default_options()
-        o60.max_iter = 300
-        m60 = ltompc.BatchedMPC(tables, n_horizon=60, batch=1, options=o60, device=local_rank)
-        m60.set_stream(stream.cuda_stream)
-        x60 = ltompc.X0_REFERENCE[None].copy()
-        m60.set_initial_guess(x60)
-        t60, bad60, it60 = 0.0, 0, 0
-        for _ in range(300):
-            tb = time.perf_counter()
-            u60 = m60.make_step(x60)
-            t60 += time.perf_counter() - tb
-            bad60 += int(m60.status[0] != 0)
-            it60 += int(m60.iters[0])
-            x60 = m60.plant_step(x60, u60)
-        extras["closed_loop_n60"] = {"ticks": 300, "simulated_s": 30.0, "solve_wall_s": t60, "real_time_factor": 30.0 / t60,
-                                     "s_reached_m": float(x60[0, 0]), "non_converged_ticks": bad60, "ip_iters_mean": it60 / 300.0}
-        m60.close()
-        # ... and the whole lap with the track constraints softened (options.soft_rho = 100, do_mpc's soft_constraint /
-        # penalty_term_cons; an extension: the reference's hard constraints stop the loop part-way): until the horizon
-        # reaches the end of the tables
-        o60.soft_rho = 100.0
         m60 = ltompc.BatchedMPC(tables, n_horizon=60, batch=1, options=o60, device=local_rank)
         m60.set_stream(stream.cuda_stream)
         x60 = ltompc.X0_REFERENCE[None].copy()
         m60.set_initial_guess(x60)
         s_end = tables.s_max - 0.1 * 60 * 25.0
-        t60, bad60, it60, n60 = 0.0, 0, 0, 0
+        t60, it60, n60, h60 = 0.0, 0, 0, {}
         while x60[0, 0] < s_end and n60 < 1500:
             tb = time.perf_counter()
             u60 = m60.make_step(x60)
             t60 += time.perf_counter() - tb
-            bad60 += int(m60.status[0] != 0)
+            h60[int(m60.status[0])] = h60.get(int(m60.status[0]), 0) + 1
             it60 += int(m60.iters[0])
             x60 = m60.plant_step(x60, u60)
             n60 += 1
-        extras["closed_loop_lap_soft_n60"] = {"options": {"soft_rho": 100.0}, "ticks": n60, "simulated_s": 0.1 * n60, "solve_wall_s": t60,
-                                              "real_time_factor": 0.1 * n60 / t60, "s_reached_m": float(x60[0, 0]),
-                                              "s_target_m": float(s_end), "non_converged_ticks": bad60, "ip_iters_mean": it60 / max(n60, 1)}
+        extras["closed_loop_lap_n60"] = {"constraints": "hard (reference)", "ticks": n60, "simulated_s": 0.1 * n60, "solve_wall_s": t60,
+                                         "real_time_factor": 0.1 * n60 / t60, "s_reached_m": float(x60[0, 0]), "s_target_m": float(s_end),
+                                         "status_histogram": {STATUS_NAMES[k]: v for k, v in sorted(h60.items())}, "ip_iters_mean": it60 / max(n60, 1)}
         m60.close()
 
-    # ---- same workload with the warm start tuned for MPC (extension, not the reference's solver settings): previous
-    #      solution shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same
-    #      tolerance; reported as an extra, the headline `value` keeps do_mpc/IPOPT's defaults.
-    if rank == 0 and not args.no_extras:
-        to = ltompc.default_options()
-        to.max_iter, to.warm_shift, to.mu_init_warm = args.max_iter, 1, 1e-3
-        mt = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=to, device=local_rank)
-        mt.set_stream(stream.cuda_stream)
-        xt = torch.from_numpy(x0_host).to(dev)
-        xtn, ut = torch.empty_like(xt), torch.zeros(B, 2, dtype=torch.float64, device=dev)
-        mt.set_initial_guess_dev(xt.data_ptr())
-        launched = []
-        for s in range(args.warmup + args.steps):
-            if s == args.warmup:
-                torch.cuda.synchronize(dev)
-                tt = time.perf_counter()
-            mt.make_step_dev(xt.data_ptr(), ut.data_ptr())
-            mt.plant_step_dev(xt.data_ptr(), ut.data_ptr(), xtn.data_ptr(), PLANT_SUBSTEPS)
-            xt, xtn = xtn, xt
-            launched.append(mt.timing()["ip_iterations"])
-        torch.cuda.synchronize(dev)
-        tt = time.perf_counter() - tt
-        stt = mt.stats()
-        extras["tuned_warm_start"] = {"options": {"warm_shift": 1, "mu_init_warm": 1e-3}, "solves_per_s": B * args.steps / tt,
-                                      "ms_per_step": 1e3 * tt / args.steps, "solved_frac_last_tick": float((stt["status"] == 0).mean()),
-                                      "ip_iters_mean_last_tick": float(stt["iters"].mean()),
-                                      "ip_iterations_launched_per_tick": launched[args.warmup:]}
-        mt.close()
+        def side_run(o, label, note):
+            mt = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=o, device=local_rank)
+            mt.set_stream(stream.cuda_stream)
+            xt = torch.from_numpy(x0_host).to(dev)
+            xtn, ut = torch.empty_like(xt), torch.zeros(B, 2, dtype=torch.float64, device=dev)
+            mt.set_initial_guess_dev(xt.data_ptr())
+            launched, conv = [], 0
+            for s in range(args.warmup + args.steps):
+                if s == args.warmup:
+                    torch.cuda.synchronize(dev)
+                    tt = time.perf_counter()
+                mt.make_step_dev(xt.data_ptr(), ut.data_ptr())
+                mt.plant_step_dev(xt.data_ptr(), ut.data_ptr(), xtn.data_ptr(), PLANT_SUBSTEPS)
+                xt, xtn = xtn, xt
+                if s >= args.warmup:
+                    c, _ = mt.status_counts()
+                    conv += int(c[0] + c[1])
+                    launched.append(mt.timing()["ip_iterations"])
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter() - tt
+            c, isum = mt.status_counts()
+            extras[label] = {"options": note, "converged_solves_per_s": conv / tt, "ms_per_step": 1e3 * tt / args.steps,
+                             "converged_frac_last_tick": float(c[0] + c[1]) / B, "ip_iters_mean_last_tick": isum / B,
+                             "ip_iterations_launched_per_tick": launched}
+            mt.close()
+        # the same workload at round 1's iteration budget (150 instead of the reference's 1000)
+        o150 = ltompc.default_options(); o150.max_iter, o150.soft_rho = 150, args.soft_rho
+        side_run(o150, "max_iter_150", {"max_iter": 150})
+        # ... and with the warm start tuned for MPC (extension, not the reference's solver settings): previous solution
+        # shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same tolerance.
+        to = ltompc.default_options(); to.max_iter, to.warm_shift, to.mu_init_warm = args.max_iter, 1, 1e-3
+        side_run(to, "tuned_warm_start", {"warm_shift": 1, "mu_init_warm": 1e-3})
 
-    # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on the host cores, bounded sample
+    # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on ALL host cores, on the states, warm starts and
+    #      previous controls the GPU handle holds after the timed region (i.e. the tick the GPU would solve next)
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle as orc
         ncores = os.cpu_count() or 1
-        nthreads = min(ncores, 16)
-        S = min(args.cpu_sample, B)
+        try:
+            nthreads = len(os.sched_getaffinity(0))
+        except AttributeError:
+            nthreads = ncores
+        S = args.cpu_sample if args.cpu_sample > 0 else min(B, max(256, 600 * nthreads))  # ~60 solves/s per core: ~10 s
+        S = min(S, B)
         oo = orc.default_options()
         oo.max_iter, oo.soft_rho = args.max_iter, args.soft_rho
         O = orc.Oracle(tables.packed(), options=oo)
-        xs = x0_host[:S]
-        r = O.solve(xs, N, nthreads=nthreads)  # cold start, untimed (creates the warm start)
-        xs1 = O.plant_step(xs, r["u0"])
+        it = mpc.iterate()                      # the GPU's last solutions: the oracle's warm start
+        st = mpc.stats()
+        xs = x.cpu().numpy()[:S]                # states after the last timed tick
+        up = u.cpu().numpy()[:S]                # controls applied last (u_prev of the next solve)
+        warm = {k: it[k][:S] for k in ("X", "C", "U", "L1", "L2")}
         tc = time.perf_counter()
-        r2 = O.solve(xs1, N, uprev=r["u0"], warm=r, nthreads=nthreads)
+        r2 = O.solve(xs, N, uprev=up, warm=warm, nthreads=nthreads, prev_status=st["status"][:S])
         tcpu = time.perf_counter() - tc
-        cpu = {"value": S / tcpu, "unit": "MPC solves/s", "cores": nthreads, "kind": "port",
-               "sample": f"{S} instances of the same batch, N={N}, one warm tick, OpenMP over instances "
-                         f"({nthreads} threads of {ncores} host cores), {tcpu:.1f}s wall; oracle/ltompc_oracle.c "
-                         "(do_mpc/IPOPT itself is not installable offline)",
-               "iters_mean": float(r2["iters"].mean()), "solved_frac": float((r2["status"] == 0).mean())}
+        conv = int(np.isin(r2["status"], (0, 1)).sum())
+        cpu = {"value": conv / tcpu, "unit": "MPC solves/s", "cores": nthreads, "kind": "port",
+               "sample": f"{S} instances of the same batch: the tick after the timed region (the GPU's states, warm starts and u_prev), N={N}, "
+                         f"OpenMP over instances, {nthreads} threads (os.cpu_count() = {ncores}), {tcpu:.1f} s wall; converged solves counted; "
+                         "oracle/ltompc_oracle.c (do_mpc/IPOPT itself is not installable offline)",
+               "attempted_per_s": S / tcpu, "iters_mean": float(r2["iters"].mean()), "converged_frac": conv / S}
         # the reference's own mode of operation is one process, one instance at a time: same oracle, one thread
         S1 = min(64, S)
-        w1 = {k: r[k][:S1] for k in ("X", "C", "U", "L1", "L2")}
+        w1 = {k: warm[k][:S1] for k in warm}
         tc = time.perf_counter()
-        O.solve(xs1[:S1], N, uprev=r["u0"][:S1], warm=w1, nthreads=1)
-        cpu["single_thread_value"] = S1 / (time.perf_counter() - tc)
+        r1 = O.solve(xs[:S1], N, uprev=up[:S1], warm=w1, nthreads=1, prev_status=st["status"][:S1])
+        cpu["single_thread_value"] = int(np.isin(r1["status"], (0, 1)).sum()) / (time.perf_counter() - tc)
         cpu["single_thread_sample"] = f"first {S1} instances of the same tick, 1 thread"
 
     if rank == 0:
+        hist_last = {STATUS_NAMES[k]: int(v) for k, v in enumerate(counts[-1]) if v}
         out = {
             "metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": value, "unit": "MPC solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -328,10 +422,14 @@ def main():
             "config": {"workload": f"batch={B} per GPU x {world} GPU, horizon N={N}, closed-loop warm ticks "
                                    f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
                        "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
-            "solved_frac_last_tick": n_solved_last / (B * world),
-            "ip_iters_mean_last_tick": iters_last / (B * world),
-            "ip_iterations_launched_per_tick": per_tick,
+                       "resto_rho": opts.resto_rho, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "value_counts": "converged solves only (status solved / acceptable)",
+            "solves_attempted_per_s": attempted,
+            "solved_frac_per_tick": [round(float(v) / n_all, 5) for v in converged_per_tick],
+            "solved_frac_last_tick": float(converged_per_tick[-1]) / n_all,
+            "status_histogram_last_tick": hist_last,
+            "ip_iters_mean_per_tick": [round(float(v) / n_all, 3) for v in itersum],
+            "ip_iterations_launched_per_tick": per_tick_iters,
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(out))

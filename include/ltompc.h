@@ -221,6 +221,18 @@ int ltompc_get_timing(ltompc_handle h, double* ms_by_kernel8, int* launches_by_k
  * and device time in ms.  Returns the number of log entries (copies at most `capacity`); negative on error. */
 int ltompc_get_launch_log(ltompc_handle h, int* kind, int* width, double* ms, int capacity);
 
+/* Interior-point iteration (0-based, within its make_step) of every entry of the launch log; returns the number of entries. */
+int ltompc_get_launch_log_iterations(ltompc_handle h, int* iteration, int capacity);
+
+/* Number of unfinished instances after every iteration of the last make_step (entry i: instances that passed the
+ * termination test of iteration i and went on); returns the number of iterations launched. */
+int ltompc_get_active_history(ltompc_handle h, int* active, int capacity);
+
+/* Histogram of the per-instance statuses of the last solve (counts8[s], s = LTOMPC_STATUS_*; entry 7 collects anything
+ * else) and the sum of the instances' iteration counts, reduced on the device: cheaper than ltompc_get_stats and does
+ * not disturb the packed order of the instances.  Either output may be NULL. */
+int ltompc_get_status_counts(ltompc_handle h, int* counts8, long long* iterations_sum);
+
 /* Poll history of the last make_step: up to `capacity` triples (iteration, unfinished instances, launch width);
  * returns the number of polls (>= 0). */
 int ltompc_get_history(ltompc_handle h, int* triples, int capacity);

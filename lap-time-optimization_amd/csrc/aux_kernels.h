@@ -223,6 +223,16 @@ __global__ void k_store_u0(Work W, double* __restrict__ u0_rm, const int* __rest
   W.uprev[b] = a, W.uprev[(size_t)W.Bp + b] = c;
 }
 
+// histogram of the statuses of the last solve (order of the instances does not matter: no un-packing needed) and the
+// total number of interior-point iterations
+__global__ void k_status_counts(Work W, int* __restrict__ counts, unsigned long long* __restrict__ iters_sum) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  const int s = W.si[(size_t)SI_STATUS * W.Bp + b];
+  atomicAdd(&counts[s < 0 ? 7 : (s > 7 ? 7 : s)], 1);
+  atomicAdd(iters_sum, (unsigned long long)W.si[(size_t)SI_ITERS * W.Bp + b]);
+}
+
 // plant: classical RK4 with n_sub sub-steps, zero-order-hold input (do_mpc Simulator / CVODES stand-in)
 __global__ void k_plant(Consts K, int B, const double* __restrict__ x, const double* __restrict__ u, double dt,
                         int n_sub, double* __restrict__ xn) {

@@ -61,10 +61,12 @@ struct ltompc_solver {
   // duration is the time to the next event.  Events come from a pool that lives as long as the handle.
   std::vector<hipEvent_t> ev, ev_pool;
   size_t ev_pool_used = 0;
-  std::vector<int> ev_kind, ev_width;
-  std::vector<int> log_kind, log_width;  // per launch of the profiled make_steps since profiling was switched on
+  std::vector<int> ev_kind, ev_width, ev_iter;
+  std::vector<int> log_kind, log_width, log_iter;  // per launch of the profiled make_steps since profiling was switched on
   std::vector<double> log_ms;
   int cur_width = 0;  // instances in the launches being issued
+  int cur_iter = 0;   // interior-point iteration the launches being issued belong to
+  int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum (k_status_counts)
   double ms_by_kernel[NKERN] = {};
   int launches_by_kernel[NKERN] = {};
   Consts* d_K = nullptr;  // device copies of K and W for the solver kernels
@@ -123,7 +125,7 @@ struct Launcher {
     }
     hipEvent_t e = h->ev_pool[h->ev_pool_used++];
     if (hipEventRecord(e, h->stream) != hipSuccess) return fail("hipEventRecord failed");
-    h->ev.push_back(e), h->ev_kind.push_back(kind), h->ev_width.push_back(h->cur_width);
+    h->ev.push_back(e), h->ev_kind.push_back(kind), h->ev_width.push_back(h->cur_width), h->ev_iter.push_back(h->cur_iter);
     return 0;
   }
   int close() { return (h->profiling && !h->ev_kind.empty() && h->ev_kind.back() >= 0) ? stamp(-1) : 0; }
@@ -152,9 +154,9 @@ int collect_profile(ltompc_solver* h) {
     HIPCHECK(hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
     h->ms_by_kernel[h->ev_kind[i]] += ms;
     h->launches_by_kernel[h->ev_kind[i]] += 1;
-    h->log_kind.push_back(h->ev_kind[i]), h->log_width.push_back(h->ev_width[i]), h->log_ms.push_back(ms);
+    h->log_kind.push_back(h->ev_kind[i]), h->log_width.push_back(h->ev_width[i]), h->log_iter.push_back(h->ev_iter[i]), h->log_ms.push_back(ms);
   }
-  h->ev.clear(), h->ev_kind.clear(), h->ev_width.clear();
+  h->ev.clear(), h->ev_kind.clear(), h->ev_width.clear(), h->ev_iter.clear();
   h->ev_pool_used = 0;
   return 0;
 }
@@ -321,6 +323,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
+  rc |= h->dalloc(&h->d_counts, 16);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
@@ -379,7 +382,7 @@ int ltompc_set_profiling(ltompc_handle h, int on) {
   if (on < 0 || on >= 2 + NKERN) return fail("ltompc_set_profiling: mode out of range");
   h->profiling = on;
   for (int i = 0; i < NKERN; i++) h->ms_by_kernel[i] = 0, h->launches_by_kernel[i] = 0;
-  h->log_kind.clear(), h->log_width.clear(), h->log_ms.clear();
+  h->log_kind.clear(), h->log_width.clear(), h->log_iter.clear(), h->log_ms.clear();
   return 0;
 }
 
@@ -443,6 +446,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   int ls_width = h->ls_width_env ? h->ls_width_env : 512;  // until the first poll of this solve
   for (;; it++) {
     const int np = la.n_pad;
+    h->cur_iter = it;
     la.force_eval = force_eval_next ? 1 : 0;
     force_eval_next = false;
     if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->ref_eval ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
@@ -673,6 +677,41 @@ int ltompc_get_launch_log(ltompc_handle h, int* kind, int* width, double* ms, in
     if (ms) ms[i] = h->log_ms[i];
   }
   return n;
+}
+
+int ltompc_get_launch_log_iterations(ltompc_handle h, int* iteration, int capacity) {
+  if (!h) return fail("null handle");
+  const int n = (int)h->log_iter.size();
+  for (int i = 0; i < n && i < capacity; i++)
+    if (iteration) iteration[i] = h->log_iter[i];
+  return n;
+}
+
+int ltompc_get_active_history(ltompc_handle h, int* active, int capacity) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  const int n = std::min(h->last_iterations, h->max_iter + 2);
+  if (active && capacity > 0) {
+    HIPCHECK(hipMemcpyAsync(active, h->W.active, sizeof(int) * std::min(n, capacity), hipMemcpyDeviceToHost, h->stream));
+    HIPCHECK(hipStreamSynchronize(h->stream));
+  }
+  return n;
+}
+
+int ltompc_get_status_counts(ltompc_handle h, int* counts8, long long* iterations_sum) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  HIPCHECK(hipMemsetAsync(h->d_counts, 0, sizeof(int) * 16, h->stream));
+  hipLaunchKernelGGL(k_status_counts, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_counts,
+                     reinterpret_cast<unsigned long long*>(h->d_counts + 8));
+  HIPCHECK(hipGetLastError());
+  int host[16];
+  HIPCHECK(hipMemcpyAsync(host, h->d_counts, sizeof host, hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < 8; i++)
+    if (counts8) counts8[i] = host[i];
+  if (iterations_sum) std::memcpy(iterations_sum, host + 8, sizeof(long long));
+  return 0;
 }
 
 int ltompc_get_history(ltompc_handle h, int* triples, int capacity) {

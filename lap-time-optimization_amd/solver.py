@@ -122,13 +122,30 @@ class BatchedMPC:
         return dict(ms={n: float(m) for n, m in zip(names, ms)}, launches_by_kernel={n: int(v) for n, v in zip(names, ln)},
                     launches=launches.value, ip_iterations=its.value)
 
-    def launch_log(self):
-        """(kind, width, ms) arrays of every kernel launch of the profiled make_steps (set_profiling(True))."""
+    def launch_log(self, with_iterations: bool = False):
+        """(kind, width, ms[, iteration]) arrays of every kernel launch of the profiled make_steps (set_profiling(True))."""
         L = lib()
         n = L.ltompc_get_launch_log(self._h, None, None, None, 0)
         kind, width, ms = np.empty(n, dtype=np.int32), np.empty(n, dtype=np.int32), np.empty(n)
         L.ltompc_get_launch_log(self._h, iptr(kind), iptr(width), dptr(ms), n)
-        return kind, width, ms
+        if not with_iterations:
+            return kind, width, ms
+        it = np.empty(n, dtype=np.int32)
+        L.ltompc_get_launch_log_iterations(self._h, iptr(it), n)
+        return kind, width, ms, it
+
+    def active_history(self):
+        """Unfinished instances after every interior-point iteration of the last make_step."""
+        n = lib().ltompc_get_active_history(self._h, None, 0)
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        lib().ltompc_get_active_history(self._h, iptr(a), n)
+        return a[:n]
+
+    def status_counts(self):
+        """(histogram of the statuses of the last solve [8], sum of the iteration counts), reduced on the device."""
+        c, s = np.zeros(8, dtype=np.int32), C.c_longlong()
+        check(lib().ltompc_get_status_counts(self._h, iptr(c), C.byref(s)))
+        return c, int(s.value)
 
     def history(self):
         buf = np.zeros((4096, 3), dtype=np.int32)

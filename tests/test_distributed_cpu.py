@@ -6,6 +6,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
 
@@ -53,3 +54,33 @@ def test_shard_ranges_cover_the_batch(pkg):
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_launcher_starts_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2 ...` (the driver's command, no torchrun around it): bench.py starts the two ranks as a child
+    process group, every rank joins the rendezvous, the barrier-bracketed time is the max over ranks, the counts are summed
+    over ranks, and rank 0's one JSON line comes back through the parent with n_gpus = world size.  The solver is replaced by
+    a stand-in (--selftest-stub, gloo): this covers the plumbing, not the numbers."""
+    import json
+    env = dict(os.environ, MASTER_PORT="29547", OMP_NUM_THREADS="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "100",
+                          "--selftest-stub"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["data"] == "stub"
+    assert r["converged_solves"] == 3 * (100 + 99)            # summed over the ranks (rank 1 "fails" one instance per tick)
+    assert r["ms_per_step"] >= 4.0                              # the slower rank (2 x 2 ms per tick) sets the time
+    assert r["value"] == pytest.approx(r["converged_solves"] / (r["ms_per_step"] * 3e-3), rel=1e-9)
+    # one rank: no child process, same line format
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "10", "--selftest-stub"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
