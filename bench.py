@@ -71,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--max-iter", type=int, default=1000, help="interior-point iteration budget per solve (reference: ipopt.max_iter = 1000, controller.py:18)")
     ap.add_argument("--soft-rho", type=float, default=0.0, help="options.soft_rho for the timed run and the CPU baseline (extension: "
                     "softened track constraints; 0 = the reference's hard constraints)")
+    ap.add_argument("--resto-sticky", type=int, default=0, help="options.resto_sticky for the timed run and the CPU baseline (extension: instances "
+                    "that needed the restoration phase start their next solves in elastic mode; 0 = every solve starts on the hard constraints)")
     ap.add_argument("--poll-every", type=int, default=4, help="iterations between two read-backs of the number of unfinished instances")
     ap.add_argument("--cpu-sample", type=int, default=0, help="instances solved by the CPU oracle for cpu_baseline (0: sized for ~10 s on the host's cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +173,7 @@ def main():
     tables = ltompc.build_tables()  # buckmore / MX-5 / curvature race line (the only one the reference MPC runs on)
     B, N = args.batch, args.horizon
     opts = ltompc.default_options()
-    opts.max_iter, opts.soft_rho = args.max_iter, args.soft_rho
+    opts.max_iter, opts.soft_rho, opts.resto_sticky = args.max_iter, args.soft_rho, args.resto_sticky
     mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
     stream = torch.cuda.current_stream(dev)
     mpc.set_stream(stream.cuda_stream)
@@ -422,7 +424,7 @@ def main():
             "config": {"workload": f"batch={B} per GPU x {world} GPU, horizon N={N}, closed-loop warm ticks "
                                    f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
                        "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
-                       "resto_rho": opts.resto_rho, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "resto_rho": opts.resto_rho, "resto_sticky": args.resto_sticky, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "value_counts": "converged solves only (status solved / acceptable)",
             "solves_attempted_per_s": attempted,
             "solved_frac_per_tick": [round(float(v) / n_all, 5) for v in converged_per_tick],

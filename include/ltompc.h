@@ -123,6 +123,13 @@ typedef struct ltompc_options {
                              residuals of the trial point added (same KKT matrix, new right-hand side: a Riccati sweep
                              over the vectors only).  Implemented in the oracle, where it was measured not to change
                              the iteration counts of this NLP; the device library accepts 0 only    (0) */
+  int resto_sticky;       /* > 0: an instance whose solve entered the restoration phase from the hard constraints, or ended
+                             INFEASIBLE, starts its next resto_sticky warm-started solves directly in elastic mode (no
+                             second jam on the hard constraints first: 10 - 15 iterations saved per solve, and these are
+                             the instances that make the tail of a tick); the count is renewed while that keeps
+                             happening.  A solve that starts in elastic mode ends like any restoration: back on the hard
+                             constraints when every elastic variable is <= tol (status SOLVED), INFEASIBLE otherwise.
+                             0: every solve starts on the hard constraints (IPOPT).                              (0) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),

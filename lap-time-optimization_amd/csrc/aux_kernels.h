@@ -32,7 +32,14 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   // Option warm_reset_on_fail: the multipliers of a solve that did not converge are not worth starting from (they are
   // what diverged): keep its primal point, restart the equality multipliers at 0 and the barrier at the cold mu_init.
   const int prev = W.si[(size_t)SI_PREV * W.Bp + b];
-  const bool after_failure = !cold && K.o.warm_reset_on_fail && prev != LTOMPC_STATUS_SOLVED && prev != LTOMPC_STATUS_ACCEPTABLE;
+  // Option resto_sticky: an instance that jammed on the hard constraints or whose horizon problem was infeasible starts
+  // its next solves in the restoration phase's elastic mode (the counter is kept by k_load_x0); the multipliers of a
+  // converged ELASTIC problem (status INFEASIBLE) are then re-used like any others.
+  const bool resto_ok = K.o.resto_rho > 0.0 && !(K.o.soft_rho > 0.0);
+  const bool start_elastic = !cold && resto_ok && K.o.resto_sticky > 0 && W.si[(size_t)SI_STICKY * W.Bp + b] > 0;
+  const bool prev_conv = prev == LTOMPC_STATUS_SOLVED || prev == LTOMPC_STATUS_ACCEPTABLE ||
+                         (prev == LTOMPC_STATUS_INFEASIBLE && K.o.resto_sticky > 0);
+  const bool after_failure = !cold && K.o.warm_reset_on_fail && !prev_conv;
   if (after_failure) {
 #pragma unroll
     for (int i = 0; i < 8; i++) PL(W.L1, i, k, N) = 0.0, PL(W.L2, i, k, N) = 0.0;
@@ -43,7 +50,7 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
   const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
-  const double rho = K.o.soft_rho;  // (the restoration phase replaces it per instance, see d_pick)
+  const double rho = start_elastic ? K.o.resto_rho : K.o.soft_rho;  // (the restoration phase replaces it per instance, see d_pick)
   init_slot_slacks<BoundsAny>(K, W, k, b, mu, eps, rho, xp, c, u);
   if (k == 0) {
     double* st = W.st;
@@ -56,8 +63,9 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
     st[(size_t)ST_C00 * W.Bp + b] = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
     st[(size_t)ST_RHO * W.Bp + b] = rho, st[(size_t)ST_VIOL * W.Bp + b] = 0.0;
     for (int i = 0; i < SI_NF; i++)
-      if (i != SI_PREV) W.si[(size_t)i * W.Bp + b] = 0;
+      if (i != SI_PREV && (i != SI_STICKY || cold)) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
+    if (start_elastic) W.si[(size_t)SI_RESTO * W.Bp + b] = 1, W.si[(size_t)SI_NRESTO * W.Bp + b] = 1, W.si[(size_t)SI_STARTEL * W.Bp + b] = 1;
   }
 }
 
@@ -199,13 +207,21 @@ __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restri
 // ------------------------------------------------------------------------------------------ I/O helpers
 // row-major (B x 8) user buffer -> [8][Bp] planes
 // (orig != nullptr: the instances are in packed order, slot b holds the caller's instance orig[b])
-__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* __restrict__ orig) {
+// (sticky: options.resto_sticky, 0 = off; update = 0 when called for set_initial_guess, whose k_init resets the counter)
+__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* __restrict__ orig, int sticky, int update) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= W.B) return;
   const size_t r = orig ? orig[b] : b;
 #pragma unroll
   for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[r * 8 + i];
-  W.si[(size_t)SI_PREV * W.Bp + b] = W.si[(size_t)SI_STATUS * W.Bp + b];  // k_init resets the rest
+  const int prev = W.si[(size_t)SI_STATUS * W.Bp + b];
+  W.si[(size_t)SI_PREV * W.Bp + b] = prev;  // k_init resets the rest
+  if (update && sticky > 0) {
+    // jammed on the hard constraints (restoration entered from them) or infeasible: the next `sticky` solves start elastic
+    const bool jammed = W.si[(size_t)SI_NRESTO * W.Bp + b] > 0 && !W.si[(size_t)SI_STARTEL * W.Bp + b];
+    const int c = W.si[(size_t)SI_STICKY * W.Bp + b];
+    W.si[(size_t)SI_STICKY * W.Bp + b] = (prev == LTOMPC_STATUS_INFEASIBLE || jammed) ? sticky : (c > 0 ? c - 1 : 0);
+  }
 }
 __global__ void k_zero_uprev(Work W) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;

@@ -57,7 +57,10 @@ enum : int {
 // hard constraints.  SI_REINIT: set when the phase is entered; the next evaluation kernel first re-initialises the
 // slacks / multipliers of its slot from the primal point (the Riccati head clears the flag).
 enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_STEP, SI_NREG, SI_NLSFAIL, SI_RETRY, SI_TRIES,
-             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_RESTO, SI_REINIT, SI_NRESTO, SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
+             SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_RESTO, SI_REINIT, SI_NRESTO,
+             SI_STICKY,   // option resto_sticky: solves for which the instance still starts in elastic mode (kept between make_steps)
+             SI_STARTEL,  // this solve started in elastic mode
+             SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
 
 struct Work {
   int N, B, Bp;

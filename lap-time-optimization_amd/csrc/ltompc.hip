@@ -224,7 +224,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1;
-  o->resto_rho = 1000.0, o->max_soc = 0;
+  o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
@@ -237,6 +237,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (!(options->t_step > 0)) return fail("ltompc_create: t_step must be positive");
   if (!(options->soft_rho >= 0) || !std::isfinite(options->soft_rho)) return fail("ltompc_create: soft_rho must be >= 0 (0 = hard track constraints)");
   if (!(options->resto_rho >= 0) || !std::isfinite(options->resto_rho)) return fail("ltompc_create: resto_rho must be >= 0 (0 = no restoration phase)");
+  if (options->resto_sticky < 0) return fail("ltompc_create: resto_sticky must be >= 0");
   if (options->max_soc != 0) return fail("ltompc_create: max_soc must be 0 (the second-order correction exists in the oracle only, see include/ltompc.h)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
     for (int i = 0; i < n_table; i++)
@@ -361,12 +362,12 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
 
 int ltompc_destroy(ltompc_handle h) {
   if (!h) return 0;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  for (void* p : h->allocs) hipFree(p);
-  for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-  if (h->h_active) hipHostFree(h->h_active);
-  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->h_active) (void)hipHostFree(h->h_active);
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
   return 0;
 }
@@ -396,7 +397,7 @@ int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev) {
   if (!h || !x0_dev) return fail("ltompc_set_initial_guess: null argument");
   HIPCHECK(hipSetDevice(h->device));
   h->packed = false;  // a cold start overwrites the whole iterate: nothing to restore
-  hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)nullptr);
+  hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)nullptr, 0, 0);
   hipLaunchKernelGGL(k_zero_uprev, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W);
   hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, 1);
   HIPCHECK(hipGetLastError());
@@ -419,7 +420,8 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   HIPCHECK(hipSetDevice(h->device));
   const int B = h->B, N = h->N, Bp = h->Bp;
   Launcher L{h};
-  hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)(h->packed ? h->d_orig : nullptr));
+  hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)(h->packed ? h->d_orig : nullptr),
+                     h->K.o.resto_sticky, h->cold_next ? 0 : 1);
   if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
   if (!h->cold_next && h->K.o.warm_shift) {
     hipLaunchKernelGGL(k_shift, dim3(((N + 1) * Bp + 63) / 64), dim3(64), 0, h->stream, h->W, 0);
@@ -760,7 +762,7 @@ int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const
                      dev[4], dev[5], dev[6], dev[7], dev[8], dev[9], dev[10]);
   HIPCHECK(hipStreamSynchronize(h->stream));
   for (int i = 0; i < 9; i++) HIPCHECK(hipMemcpy(dst[i], dev[2 + i], sizeof(double) * sizes[2 + i] * n, hipMemcpyDeviceToHost));
-  for (int i = 0; i < 11; i++) hipFree(dev[i]);
+  for (int i = 0; i < 11; i++) (void)hipFree(dev[i]);
   return 0;
 }
 

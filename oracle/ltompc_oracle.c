@@ -997,8 +997,11 @@ static void init_slacks(ipws* s) {
   }
 }
 
+/* warm: 0 cold start (do_mpc set_initial_guess) | 1 from the previous solution | 2 from its primal point only (option
+ * warm_reset_on_fail after a solve that did not converge: multipliers 0, barrier at mu_init).  start_elastic: option
+ * resto_sticky, the solve starts in the restoration phase's elastic mode. */
 static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
-                     const double* uprev, int warm, double* X, double* C, double* U, double* L1, double* L2,
+                     const double* uprev, int warm, int start_elastic, double* X, double* C, double* U, double* L1, double* L2,
                      double* Tout, double* NUout, solve_stats* st) {
   ipws S;
   ipws* s = &S;
@@ -1054,11 +1057,13 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       memcpy(it->x + (N - 1) * NX, X + N * NX, sizeof(double) * NX);
     }
     memcpy(it->x, x0, sizeof(double) * NX); /* node 0 is the measured state */
+    if (warm == 2) memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
   }
-  double mu = (warm && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
+  double mu = (warm == 1 && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
   s->mu = mu;
   Tl.eps_s = SMOOTHING(mu);
   init_slacks(s);
+  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0;
 
   /* filter */
   double filt_th[FILTER_MAX], filt_ph[FILTER_MAX];
@@ -1067,11 +1072,15 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   double delta_w_last = 0.0;
   int status = LTOMPC_STATUS_MAX_ITER, iter = 0, n_acc = 0;
   double E0 = INFINITY, obj = 0;
-  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0;
   double force_reg = 0.0;
   /* restoration (elastic mode): 0 = not entered, 1 = solving the elastic problem, 2 = back on the hard constraints */
   int resto = 0;
   const int resto_allowed = o->resto_rho > 0 && !(o->soft_rho > 0);
+  if (start_elastic && resto_allowed && warm) { /* (slacks and elastic variables below: init_slacks with rho = resto_rho) */
+    resto = 1, st->n_resto = 1;
+    it->rho = tr->rho = o->resto_rho;
+    init_slacks(s);
+  }
 
   double eps_next = Tl.eps_s;
   int n_tiny = 0;
@@ -1434,7 +1443,7 @@ void oracle_default_options(ltompc_options* o) {
   o->t_step = 0.1, o->tol = 1e-8, o->acceptable_tol = 1e-6, o->mu_init = 0.1, o->mu_min = 1e-9;
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
-  o->resto_rho = 1000.0, o->max_soc = 0;
+  o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
   o->warm_reset_on_fail = 1; /* applied by the caller (oracle.py solve(prev_status=...)): this file sees one solve at a time */
 }
 
@@ -1530,7 +1539,10 @@ int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const d
  * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol => 10 doubles per instance. */
 int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const double* tab, int nt, int N, int B,
                        const double* x0, const double* uprev, int warm, double* X, double* C, double* U,
-                       double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout) {
+                       double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout,
+                       const int* prev_status, int* sticky) {
+  /* prev_status (may be NULL): status of the solve the warm start comes from, per instance (option warm_reset_on_fail).
+   * sticky (may be NULL; in/out): option resto_sticky, ticks for which an instance still starts in elastic mode. */
   bounds_t bd0;
   build_bounds(p, &bd0);
   const int ni0 = bd0.ni;
@@ -1543,9 +1555,24 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
 #endif
   for (int b = 0; b < B; b++) {
     solve_stats st;
-    solve_one(p, o, &T, N, x0 + (size_t)b * NX, uprev + (size_t)b * NU, warm, X + (size_t)b * (N + 1) * NX,
+    int w = warm ? 1 : 0, start_elastic = 0;
+    if (warm && prev_status) {
+      const int ps = prev_status[b];
+      /* with resto_sticky the multipliers of a converged ELASTIC problem (status INFEASIBLE) are re-used like any others */
+      const int conv = ps == LTOMPC_STATUS_SOLVED || ps == LTOMPC_STATUS_ACCEPTABLE || (ps == LTOMPC_STATUS_INFEASIBLE && o->resto_sticky > 0);
+      if (o->warm_reset_on_fail && !conv) w = 2;
+    }
+    if (warm && sticky && o->resto_sticky > 0 && sticky[b] > 0) start_elastic = 1;
+    solve_one(p, o, &T, N, x0 + (size_t)b * NX, uprev + (size_t)b * NU, w, start_elastic, X + (size_t)b * (N + 1) * NX,
               C + (size_t)b * N * NX, U + (size_t)b * N * NU, L1 + (size_t)b * N * NX, L2 + (size_t)b * N * NX,
               Tout ? Tout + (size_t)b * N * ni0 : NULL, NUout ? NUout + (size_t)b * N * ni0 : NULL, &st);
+    if (sticky && o->resto_sticky > 0) {
+      /* an instance that jammed on the hard constraints, or whose horizon problem is infeasible, starts its next
+       * resto_sticky solves in elastic mode */
+      const int jammed = st.n_resto > 0 && !start_elastic;
+      if (st.status == LTOMPC_STATUS_INFEASIBLE || jammed) sticky[b] = o->resto_sticky;
+      else if (sticky[b] > 0) sticky[b]--;
+    }
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
     double* s = stats + (size_t)b * 10;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;

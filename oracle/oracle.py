@@ -29,7 +29,7 @@ class Options(C.Structure):
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
         "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho", "resto_rho")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("latency_mode", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("resto_sticky", C.c_int), ("latency_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -115,37 +115,15 @@ class Oracle:
         return xn
 
     # ---- NLP solve ----------------------------------------------------------------
-    def solve(self, x0, N, uprev=None, warm=None, nthreads=0, prev_status=None):
+    def solve(self, x0, N, uprev=None, warm=None, nthreads=0, prev_status=None, sticky=None):
         """x0: (B,8).  warm: dict(X,C,U,L1,L2) of a previous solve or None (do_mpc set_initial_guess).
         prev_status: status of the solve `warm` comes from (option warm_reset_on_fail of include/ltompc.h: an instance
         whose previous solve did not converge keeps the primal point, restarts L1 = L2 = 0 and the barrier at mu_init).
-        Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail)."""
+        sticky: int32 array (B,), in/out: option resto_sticky (ticks for which an instance starts in elastic mode); the
+        caller keeps it between ticks (the device library keeps it in the handle).
+        Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail, n_soc, n_resto, viol)."""
         x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
         B = x0.shape[0]
-        if warm is not None and prev_status is not None and self.o.warm_reset_on_fail:
-            bad = ~np.isin(np.asarray(prev_status).reshape(B), (0, 1))
-            if bad.any():
-                up = np.zeros((B, 2)) if uprev is None else np.atleast_2d(uprev)
-                parts = []
-                for sel, reset in ((~bad, False), (bad, True)):
-                    if not sel.any():
-                        parts.append(None); continue
-                    w = {k: np.array(warm[k][sel], float) for k in ("X", "C", "U", "L1", "L2")}
-                    saved = self.o.mu_init_warm
-                    if reset:
-                        w["L1"][:] = 0.0; w["L2"][:] = 0.0; self.o.mu_init_warm = 0.0
-                    try:
-                        parts.append(self.solve(x0[sel], N, up[sel], w, nthreads))
-                    finally:
-                        self.o.mu_init_warm = saved
-                out = {}
-                ref = parts[0] or parts[1]
-                for k, v in ref.items():
-                    out[k] = np.zeros((B,) + v.shape[1:], v.dtype)
-                    for sel, part in zip((~bad, bad), parts):
-                        if part is not None:
-                            out[k][sel] = part[k]
-                return out
         uprev = np.zeros((B, 2)) if uprev is None else np.ascontiguousarray(np.atleast_2d(uprev), float)
         if warm is None:
             X, Cc, U = np.zeros((B, N + 1, 8)), np.zeros((B, N, 8)), np.zeros((B, N, 2))
@@ -155,9 +133,17 @@ class Oracle:
         u0, st = np.zeros((B, 2)), np.zeros((B, 10))
         ni = int(lib().oracle_num_ineq(C.byref(self.p)))
         Tt, Nu = np.zeros((B, N, ni)), np.zeros((B, N, ni))
+        ps = None
+        if warm is not None and prev_status is not None:
+            ps = np.ascontiguousarray(np.asarray(prev_status).reshape(B), dtype=np.int32)
+        if sticky is not None:
+            assert sticky.dtype == np.int32 and sticky.shape == (B,) and sticky.flags["C_CONTIGUOUS"]
+        ip = C.POINTER(C.c_int)
         lib().oracle_solve_batch(C.byref(self.p), C.byref(self.o), _p(self.tab), self.nt, int(N), int(B), _p(x0),
                                  _p(uprev), int(warm is not None), _p(X), _p(Cc), _p(U), _p(L1), _p(L2), _p(u0),
-                                 _p(st), int(nthreads), _p(Tt), _p(Nu))
+                                 _p(st), int(nthreads), _p(Tt), _p(Nu),
+                                 ps.ctypes.data_as(ip) if ps is not None else None,
+                                 sticky.ctypes.data_as(ip) if sticky is not None else None)
         return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
                     kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int),
                     n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9])

@@ -28,4 +28,3 @@ for t in range(K):
             print(f"    infeasible now {int((st==5).sum())}, of which infeasible last tick {int(again.sum())}; viol p50 {np.median(s['viol'][st==5]) if (st==5).any() else 0:.2e} max {s['viol'][st==5].max() if (st==5).any() else 0:.2e}")
     prev = st.copy()
     x = m.plant_step(x, u, 100)
-np.savez("gpurun_out/tail_state.npz", x=x, status=st, iters=it, viol=s["viol"], u=u, **{k: v for k, v in m.iterate().items()})

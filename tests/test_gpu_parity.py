@@ -760,3 +760,37 @@ def test_exact_piecewise_linear_tables_on_gpu(pkg, tables, orc, gpu_lib):
     ok = (d.status == 0) & (ref["status"] == 0)
     assert np.abs(ud - ref["u0"])[ok].max() < 1e-5   # the rounding moves the solution by less than the solve tolerance shows
     d.close()
+
+
+def test_sticky_elastic_start_matches_oracle(pkg, tables, orc, gpu_lib):
+    """options.resto_sticky: instances that jammed on the hard constraints or were infeasible start their next solves in
+    elastic mode.  Closed loop of a batch that contains such instances (the two stall states and cars placed close to the
+    boundaries), GPU against the oracle with the same option: statuses, restoration counts, iteration counts, controls."""
+    B, N, K = 96, 20, 8
+    x = pkg.sample_x0(tables, B, seed=51)
+    x[0], x[1] = STALL_STATES[20][0], STALL_STATES[40][0]
+    x[2:34, 1] += np.where(np.arange(32) % 2, 0.9, -0.9)   # pushed towards a boundary: restoration-prone
+    o = pkg.default_options(); o.resto_sticky = 3
+    oo = orc.default_options(); oo.resto_sticky = 3
+    oracle = orc.Oracle(tables.packed(), options=oo)
+    m = pkg.BatchedMPC(tables, N, B, options=o)
+    m.set_initial_guess(x)
+    ref, up, sticky = None, np.zeros((B, 2)), np.zeros(B, dtype=np.int32)
+    n_sticky_starts = 0
+    for tick in range(K):
+        started = sticky > 0
+        u = m.make_step(x)
+        s = m.stats()
+        ref = oracle.solve(x, N, up, ref, nthreads=8, prev_status=None if ref is None else ref["status"], sticky=sticky)
+        n_sticky_starts += int(started.sum())
+        assert (s["status"] == ref["status"]).mean() >= 0.97, (tick, np.bincount(s["status"], minlength=6), np.bincount(ref["status"], minlength=6))
+        assert (s["n_resto"] == ref["n_resto"]).mean() >= 0.97, tick
+        both = (s["status"] == 0) & (ref["status"] == 0)
+        assert np.abs(u - ref["u0"])[both].max() < 1e-5, tick
+        assert (np.abs(s["iters"] - ref["iters"])[both] <= 2).mean() >= 0.93, tick
+        if started.any():   # an elastic start ends like any restoration: SOLVED on the hard constraints or INFEASIBLE with a violation
+            assert np.all(s["n_resto"][started & (s["status"] == ref["status"])] >= 1)
+            assert np.all(s["viol"][s["status"] == 5] > o.tol)
+        x, up = oracle.plant_step(x, ref["u0"]), ref["u0"]
+    assert n_sticky_starts >= 10
+    m.close()
