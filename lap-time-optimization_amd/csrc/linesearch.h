@@ -20,12 +20,12 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
   const double eps = W.st[(size_t)ST_EPS * W.Bp + b], rho = W.st[(size_t)ST_RHO * W.Bp + b];
   double a_pri = 1.0;
-  for (int kk = 0; kk < N; kk += 8) {  // eight loads in flight per round trip (a plain loop waits for every single one)
-    double v8[8];
+  for (int kk = 0; kk < N; kk += 20) {  // twenty loads in flight per round trip (a plain loop waits for every single one)
+    double v20[20];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v8[q] = PL(W.SP, SP_apri, kk + q < N ? kk + q : N - 1, N);
+    for (int q = 0; q < 20; q++) v20[q] = PL(W.SP, SP_apri, kk + q < N ? kk + q : N - 1, N);
 #pragma unroll
-    for (int q = 0; q < 8; q++) a_pri = fmin(a_pri, v8[q]);
+    for (int q = 0; q < 20; q++) a_pri = fmin(a_pri, v20[q]);
   }
   double xk[8], xp[8], c[8], u[2], v[2], dxk[8], dxp[8], dc[8], du[2], dv[2];
 #pragma unroll
@@ -323,24 +323,50 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
   if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
   const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
   const double mu = W.st[(size_t)ST_MU * W.Bp + b];
+  // Loads in batches, stores after them: on gfx9 a load that follows a store waits for the store as well (vmcnt counts
+  // both, in order), so "load, update, store" per word is one full memory round trip per word for a lone wavefront
+  // (narrow launches: 23 round trips for the inequalities of a slot, 55 k cycles of k_step1's 140 k).
+  {
+    double x[8], dx[8], c[8], dc[8], l1[8], n1[8], l2[8], n2[8], u[2], du[2];
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
-    PL(W.X, i, k + 1, N + 1) += alpha * PL(W.dX, i, k + 1, N + 1);
-    PL(W.C, i, k, N) += alpha * PL(W.dC, i, k, N);
-    double l1 = PL(W.L1, i, k, N), l2 = PL(W.L2, i, k, N);
-    PL(W.L1, i, k, N) = l1 + alpha * (PL(W.nL1, i, k, N) - l1);
-    PL(W.L2, i, k, N) = l2 + alpha * (PL(W.nL2, i, k, N) - l2);
+    for (int i = 0; i < 8; i++) {
+      x[i] = PL(W.X, i, k + 1, N + 1), dx[i] = PL(W.dX, i, k + 1, N + 1), c[i] = PL(W.C, i, k, N), dc[i] = PL(W.dC, i, k, N);
+      l1[i] = PL(W.L1, i, k, N), n1[i] = PL(W.nL1, i, k, N), l2[i] = PL(W.L2, i, k, N), n2[i] = PL(W.nL2, i, k, N);
+    }
+    u[0] = PL(W.U, 0, k, N), u[1] = PL(W.U, 1, k, N), du[0] = PL(W.dU, 0, k, N), du[1] = PL(W.dU, 1, k, N);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      PL(W.X, i, k + 1, N + 1) = x[i] + alpha * dx[i];
+      PL(W.C, i, k, N) = c[i] + alpha * dc[i];
+      PL(W.L1, i, k, N) = l1[i] + alpha * (n1[i] - l1[i]);
+      PL(W.L2, i, k, N) = l2[i] + alpha * (n2[i] - l2[i]);
+    }
+    PL(W.U, 0, k, N) = u[0] + alpha * du[0], PL(W.U, 1, k, N) = u[1] + alpha * du[1];
   }
-  PL(W.U, 0, k, N) += alpha * PL(W.dU, 0, k, N), PL(W.U, 1, k, N) += alpha * PL(W.dU, 1, k, N);
   const int ni = K.bd.ni, nact = (k + 1 <= N - 1) ? ni : ni - 3;
-  for (int m = 0; m < nact; m++) {
-    double t = PL(W.T, m, k, N) + alpha * PL(W.dT, m, k, N);
-    double nu = PL(W.NU, m, k, N) + a_dua * PL(W.dNU, m, k, N);
-    double lo = mu / (1e10 * t), hi = 1e10 * mu / t;  // IPOPT eq. (16)
-    PL(W.T, m, k, N) = t, PL(W.NU, m, k, N) = nu < lo ? lo : (nu > hi ? hi : nu);
+  for (int m0 = 0; m0 < nact; m0 += 8) {
+    double t[8], dt[8], nu[8], dn[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int m = m0 + q < nact ? m0 + q : nact - 1;  // (the last chunk repeats its last word: branch-free loads)
+      t[q] = PL(W.T, m, k, N), dt[q] = PL(W.dT, m, k, N), nu[q] = PL(W.NU, m, k, N), dn[q] = PL(W.dNU, m, k, N);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (m0 + q < nact) {
+        const double tn = t[q] + alpha * dt[q];
+        const double nn = nu[q] + a_dua * dn[q];
+        const double lo = mu / (1e10 * tn), hi = 1e10 * mu / tn;  // IPOPT eq. (16)
+        PL(W.T, m0 + q, k, N) = tn, PL(W.NU, m0 + q, k, N) = nn < lo ? lo : (nn > hi ? hi : nn);
+      }
   }
-  if (W.st[(size_t)ST_RHO * W.Bp + b] > 0.0 && nact == ni)
-    for (int m = ni; m < ni + 3; m++) PL(W.T, m, k, N) += alpha * PL(W.dT, m, k, N);  // elastic variables
+  if (W.st[(size_t)ST_RHO * W.Bp + b] > 0.0 && nact == ni) {  // elastic variables
+    double e[3], de[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) e[q] = PL(W.T, ni + q, k, N), de[q] = PL(W.dT, ni + q, k, N);
+#pragma unroll
+    for (int q = 0; q < 3; q++) PL(W.T, ni + q, k, N) = e[q] + alpha * de[q];
+  }
 }
 
 __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
@@ -368,13 +394,23 @@ __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, co
   if (si[(size_t)SI_DONE * W.Bp + b] || !si[(size_t)SI_STEP * W.Bp + b]) return;  // block-uniform
   // all step candidates at once (the threads are there anyway; the wide path evaluates candidates 2.. only for the
   // instances that rejected the full step, with the same arithmetic)
+  // LTOMPC_DBG: shader-clock cycles of block 0 per section (own line search, all line searches, pick, update), slots 8..12
+  const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && tid == 0;
+  long long rt0 = rprof ? clock64() : 0;
+#define STOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
   for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP, false>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
+  STOCK(8);
   __syncthreads();
+  STOCK(9);
   // (phase 1 of the filter test starts with the test of the full step, i.e. it is phase 0 followed by phase 1 when the
   //  measures of all candidates exist already: one pass, same decisions)
   if (tid < 64 && (tid & 7) == 0) d_pick(K, W, b, tid >> 3, 1, false);
   __syncthreads();
+  STOCK(10);
   for (int kk = tid; kk < N; kk += 320) d_update(K, W, kk, b);
+  STOCK(11);
+  if (rprof) W.DBG[12] += 1.0;
+#undef STOCK
 }
 
 

@@ -753,16 +753,16 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   {
     const int lane = i * 8 + g;
     const int total = N * QP_NF;
-    for (int base = lane; base < total; base += 64 * 8) {  // 8 independent loads in flight per lane
-      double v[8];
+    for (int base = lane; base < total; base += 64 * 16) {  // 16 independent loads in flight per lane
+      double v[16];
 #pragma unroll
-      for (int r = 0; r < 8; r++) {
+      for (int r = 0; r < 16; r++) {
         const int idx = base + 64 * r, ic = idx < total ? idx : total - 1;
         const int kq = ic / QP_NF, fq = ic - kq * QP_NF;
         v[r] = PG(W.QP, fq, kq, QP_NF);
       }
 #pragma unroll
-      for (int r = 0; r < 8; r++)
+      for (int r = 0; r < 16; r++)
         if (base + 64 * r < total) S.q[base + 64 * r] = v[r];
     }
     for (int idx = lane; idx < N * 2; idx += 64) S.u[idx] = PL(W.U, idx & 1, idx >> 1, N);
