@@ -51,6 +51,9 @@ typedef struct ltompc_params {
   double mass, inertia_z, length_f, length_r, width;
   double B_f, C_f, D_f, B_r, C_r, D_r;
   double C_m, Cr_0, Cr_2, gravity;
+  /* Torque vectoring (model.py:162-164, disabled in the reference: `Mtv = 0.0`, the line `Mtv = ptv * (rt - r)` with
+   * rt = tan(delta) vx / (l_f + l_r) is commented out): yaw moment added to the r equation.  0 = the reference. */
+  double ptv;
   /* controller.py:29,52-53: lterm = q_n n^2 + q_mu mu^2 + q_vy vy^2 + q_v (vx - vref_scale*v_ref(s))^2
    *                                 + q_B (atan(vy/vx) - atan(delta*l_r/(l_f+l_r)))^2 ; mterm = first three.
    * controller.py:40-41 + mpc.py:104: rterm = sum_i r_du[i] * (u_k[i] - u_{k-1}[i])^2                  */

@@ -201,7 +201,7 @@ __device__ __forceinline__ void rhs_val(const ltompc_params& p, const Tables& T,
   f[2] = r - kap * sdot;
   f[3] = (Fx - Fyf * sd + p.mass * vy * r) / p.mass;
   f[4] = (Fyr + Fyf * cd - p.mass * vx * r) / p.mass;
-  f[5] = (Fyf * p.length_f * cd - Fyr * p.length_r) / p.inertia_z;
+  f[5] = (Fyf * p.length_f * cd - Fyr * p.length_r + p.ptv * (sd / cd * vx / L - r)) / p.inertia_z;  // (+ Mtv, model.py:162-164; ptv = 0 in the reference)
   f[6] = u[0];
   f[7] = u[1];
 }
@@ -282,13 +282,16 @@ __device__ __forceinline__ void rhs_derivs(const ltompc_params& p, const Tables&
   double im = 1.0 / p.mass, iz = 1.0 / p.inertia_z;
   f[3] = (p.C_m * th - p.Cr_0 - p.Cr_2 * vx * vx - Ps.v) * im + vy * r;
   f[4] = (Fr.v + Pc.v) * im - vx * r;
-  f[5] = (p.length_f * Pc.v - p.length_r * Fr.v) * iz;
+  // torque vectoring Mtv = ptv (tan(delta) vx / L - r)  (model.py:162-164; the reference has ptv = 0: every term below vanishes)
+  const double td = sd / cd, sec2 = 1.0 / (cd * cd), pz = p.ptv * iz, iL = 1.0 / L;
+  f[5] = (p.length_f * Pc.v - p.length_r * Fr.v) * iz + pz * (td * vx * iL - r);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     J[3 * 8 + 3 + j] = -Ps.g[j] * im;
     J[4 * 8 + 3 + j] = (Fr.g[j] + Pc.g[j]) * im;
     J[5 * 8 + 3 + j] = (p.length_f * Pc.g[j] - p.length_r * Fr.g[j]) * iz;
   }
+  J[5 * 8 + 3] += pz * td * iL, J[5 * 8 + 5] += -pz, J[5 * 8 + 6] += pz * vx * sec2 * iL;
   J[3 * 8 + 3] += -2.0 * p.Cr_2 * vx * im;
   J[3 * 8 + 4] += r;
   J[3 * 8 + 5] += vy;
@@ -306,6 +309,8 @@ __device__ __forceinline__ void rhs_derivs(const ltompc_params& p, const Tables&
       for (int j = 0; j <= i; j++)
         H[sidx(3 + i, 3 + j)] += cs * Ps.h[sidx(i, j)] + cc * Pc.h[sidx(i, j)] + cr * Fr.h[sidx(i, j)];
     H[sidx(3, 3)] += l3 * (-2.0 * p.Cr_2 * im);
+    H[sidx(6, 3)] += l5 * pz * sec2 * iL;                    // d2 Mtv / dvx ddelta
+    H[sidx(6, 6)] += l5 * pz * vx * 2.0 * sec2 * td * iL;    // d2 Mtv / ddelta2
     H[sidx(5, 4)] += l3;   // d2 (vy r)
     H[sidx(5, 3)] += -l4;  // d2 (-vx r)
   }

@@ -46,10 +46,13 @@ class VehicleModel:
     """Vehicle parameters (src/mpc/model.py:12-64).  Same loader semantics: JSON with // and /* */ comments,
     reads exactly the keys the reference reads; D_f, D_r are NOT read and stay 1.0."""
 
-    def __init__(self, params_file_path: str | None, track: Track):
+    def __init__(self, params_file_path: str | None, track: Track, torque_vectoring: bool = False):
+        """torque_vectoring: use the file's `ptv` in the r equation (model.py:162, `Mtv = self.ptv * (rt - r)`, which the
+        reference has commented out in favour of `Mtv = 0.0`); False = the reference's behaviour."""
         self.track = track
         self.params = _lib.default_params()
         self.load_params(params_file_path or default_vehicle_json())
+        self.params.ptv = float(self.ptv) if torque_vectoring else 0.0
 
     @staticmethod
     def remove_comments(json_str: str) -> str:

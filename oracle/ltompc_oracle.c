@@ -245,8 +245,9 @@ static void rhs_jet(const ltompc_params* p, const tables_t* T, const double* x, 
   out->f[2] = jsub(r, jmul(kap, sdot));                                            /* :170-172 */
   out->f[3] = jscale(jadd(jsub(Fx, jmul(Fyf, jsin(de))), jscale(jmul(vy, r), p->mass)), 1.0 / p->mass);
   out->f[4] = jscale(jsub(jadd(Fyr, jmul(Fyf, jcos(de))), jscale(jmul(vx, r), p->mass)), 1.0 / p->mass);
-  out->f[5] = jscale(jsub(jscale(jmul(Fyf, jcos(de)), p->length_f), jscale(Fyr, p->length_r)),
-                     1.0 / p->inertia_z); /* Mtv = 0, model.py:164 */
+  /* model.py:162-164: Mtv = ptv (rt - r), rt = tan(delta) vx / (l_f + l_r); the reference sets Mtv = 0 (ptv = 0 here) */
+  jet Mtv = jscale(jsub(jscale(jmul(jdiv(jsin(de), jcos(de)), vx), 1.0 / (p->length_f + p->length_r)), r), p->ptv);
+  out->f[5] = jscale(jadd(jsub(jscale(jmul(Fyf, jcos(de)), p->length_f), jscale(Fyr, p->length_r)), Mtv), 1.0 / p->inertia_z);
 }
 
 /* value-only rhs (plant, line search) */
@@ -266,7 +267,7 @@ static void rhs_val(const ltompc_params* p, const tables_t* T, const double* x, 
   f[2] = r - kap * sdot;
   f[3] = (Fx - Fyf * sin(de) + p->mass * vy * r) / p->mass;
   f[4] = (Fyr + Fyf * cos(de) - p->mass * vx * r) / p->mass;
-  f[5] = (Fyf * p->length_f * cos(de) - Fyr * p->length_r) / p->inertia_z;
+  f[5] = (Fyf * p->length_f * cos(de) - Fyr * p->length_r + p->ptv * (tan(de) * vx / L - r)) / p->inertia_z;
   f[6] = u[0]; /* model.py:183: rhs('steering_angle') = steering_angle_change */
   f[7] = u[1]; /* model.py:182 */
 }

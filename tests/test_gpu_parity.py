@@ -794,3 +794,37 @@ def test_sticky_elastic_start_matches_oracle(pkg, tables, orc, gpu_lib):
         x, up = oracle.plant_step(x, ref["u0"]), ref["u0"]
     assert n_sticky_starts >= 10
     m.close()
+
+
+def test_torque_vectoring_on_gpu(pkg, tables, orc, gpu_lib):
+    """params.ptv (model.py:162-164; disabled in the reference): hand-derived derivatives of the extra yaw moment against the
+    oracle's AD, and solves with ptv = 0.5 (MX5.json) against the oracle, both evaluation-kernel modes."""
+    p = pkg.default_params(); p.ptv = 0.5
+    po = orc.default_params(); po.ptv = 0.5
+    oracle = orc.Oracle(tables.packed(), params=po)
+    n = 100
+    x, lam = _points(pkg, tables, n, seed=8)
+    x[:, 6] = np.random.default_rng(1).uniform(-0.5, 0.5, n)
+    m = pkg.BatchedMPC(tables, 10, 1, params=p)
+    out = m.test_model(x, lam, 1e-4)
+    for i in range(n):
+        f, fx, H = oracle.rhs_derivs(x[i], lam[i], 1e-4)
+        assert np.abs(out["f"][i, :6] - f[:6]).max() <= 1e-11 * (1 + np.abs(f).max())
+        assert np.abs(out["J"][i] - fx).max() <= 1e-11 * (1 + np.abs(fx).max())
+        assert np.abs(out["H"][i] - H).max() <= 1e-10 * (1 + np.abs(H).max())
+    m.close()
+    B, N = 32, 20
+    x0 = pkg.sample_x0(tables, B, seed=19)
+    ref = oracle.solve(x0, N, nthreads=8)
+    base = orc.Oracle(tables.packed()).solve(x0, N, nthreads=8)
+    assert np.abs(ref["u0"] - base["u0"]).max() > 1e-4   # (the option does change the solutions)
+    for mode in (2, 1):
+        o = pkg.default_options(); o.latency_mode = mode
+        m = pkg.BatchedMPC(tables, N, B, params=p, options=o)
+        m.set_initial_guess(x0)
+        u = m.make_step(x0)
+        both = (m.status == 0) & (ref["status"] == 0)
+        assert both.mean() >= 0.95 and np.abs(u - ref["u0"])[both].max() < 1e-5, mode
+        xn = m.plant_step(x0, ref["u0"])
+        assert np.abs(xn - oracle.plant_step(x0, ref["u0"])).max() < 1e-9
+        m.close()
