@@ -96,6 +96,6 @@ def test_torque_vectoring_term(orc, tables):
     # it changes the solutions
     import importlib
     x0 = importlib.import_module("lap-time-optimization_amd").sample_x0(tables, 8, seed=19)
-    ra, rb = a.solve(x0, 10, nthreads=4), b.solve(x0, 10, nthreads=4)
+    ra, rb = a.solve(x0, 20, nthreads=4), b.solve(x0, 20, nthreads=4)
     ok = (ra["status"] == 0) & (rb["status"] == 0)
-    assert ok.sum() >= 6 and np.abs(ra["u0"] - rb["u0"])[ok].max() > 1e-4
+    assert ok.sum() >= 6 and np.abs(ra["X"] - rb["X"])[ok].max() > 1e-4   # (another predicted trajectory)
