@@ -75,6 +75,7 @@ struct ltompc_solver {
   bool ref_eval = false, ref_expand = false, ref_ls = false, ref_step1 = false;  // per kernel (LTOMPC_BOUNDS=eval,expand,...: those run generic)
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
+  int sweeps_width = 16;  // LTOMPC_SWEEPS_W: launches of at most this many instances repeat a failed Riccati sweep inside the launch (up to 4 attempts)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
@@ -292,6 +293,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     if (s1) h->step1_width = atoi(s1);
     const char* t = getenv("LTOMPC_RIC1");
     if (t) h->ric1_width = atoi(t);
+    const char* sw = getenv("LTOMPC_SWEEPS_W");
+    if (sw) h->sweeps_width = atoi(sw);
     // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
     if (ric1_lds_bytes(n_horizon) > 150 * 1024) h->ric1_width = 0;
     // (the attribute belongs to the kernel, not to the handle: always the cap, so that handles with different horizons
@@ -460,7 +463,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       const int max_sweeps = 1;
       if (n_launch <= h->ric1_width) {
         L.lds = ric1_lds_bytes(N);
-        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it)) return -1;  // one wavefront per instance
+        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;  // one wavefront per instance
       } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)

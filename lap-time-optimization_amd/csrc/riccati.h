@@ -993,14 +993,14 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, Launch la, in
 
 // One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
 // sweep, and 8 instances per wavefront make that sweep ~3x longer than it has to be).  Dynamic LDS: ric1_lds_bytes(N).
-__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, Launch la, int it_index) {
+__global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
   extern __shared__ double lds1[];
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   if ((int)blockIdx.x >= la.nact[0]) return;
   const int N = W.N;
   StageLds S{lds1, lds1 + (size_t)N * QP_NF, lds1 + (size_t)N * (QP_NF + 2)};
   Ric1Lds& L = *reinterpret_cast<Ric1Lds*>(lds1 + (size_t)N * (QP_NF + 24));
-  d_riccati1(K, W, L, S, g, i, la.act[blockIdx.x], g == 0, it_index, 1);
+  d_riccati1(K, W, L, S, g, i, la.act[blockIdx.x], g == 0, it_index, max_sweeps);
 }
 
 
