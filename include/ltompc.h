@@ -264,6 +264,28 @@ int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const
                       double* J, double* H, double* cval, double* cgrad, double* cH, double* gval,
                       double* ggrad, double* gH);
 
+/* ---------------------------------------------------------------------------------------------------------------------
+ * Velocity-profile generator: the producer of velocities.json, the v_ref table of the hot path.
+ * Replaces VelocityProfile(vehicle, s, k, s_max) of the reference (src/velocity.py:14-76, called from
+ * src/trajectory.py:47-52): local limit sqrt(mu g / k), forward pass limited by engine force and remaining traction,
+ * backward pass limited by the remaining traction, v = min of the two; a batch of independent profiles per call (the
+ * race-line optimisers evaluate one profile per candidate line).  One GPU thread per profile (the passes are sequential
+ * scans over the samples). */
+typedef struct ltompc_vp_vehicle {
+  int kind;                     /* 0: engine map + friction circle (src/vehicle.py:11-35), 1: MX-5 (src/vehicleMX5.py:11-79) */
+  int n_map;                    /* kind 0: points of the engine map (<= 16) */
+  double mass, friction_coef;   /* friction_coef: `frictionCoefficient` / `control.lambda` (local limit; kind 0: traction too) */
+  double lam, D;                /* kind 1: traction(v, k, lam=2.0): F_max = lam * D * mass * g with D = (D_f + D_r) / 2 */
+  double T, C_m, Cr_0, Cr_2;    /* kind 1: engine_force(v) = T C_m - Cr_0 - Cr_2 v^2 */
+  double map_v[16], map_f[16];  /* kind 0: engine_force(v) = np.interp(v, map_v, map_f) */
+} ltompc_vp_vehicle;
+
+/* s, k: batch x n (arc length and curvature > 0 of the samples, WITHOUT the overlapping end point of a closed path);
+ * s_max: batch (length of the closed path; < 0: open path, `s_max=None` in the reference).  Outputs batch x n, host
+ * pointers, any of v_local / v_acclim / v_declim may be NULL.  Returns 0, or < 0 with ltompc_last_error(). */
+int ltompc_velocity_profile(int device, const ltompc_vp_vehicle* vehicle, int n, int batch, const double* s, const double* k,
+                            const double* s_max, double* v, double* v_local, double* v_acclim, double* v_declim);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,4 +9,5 @@ from ._lib import LtompcError, Options, Params, default_options, default_params,
 from .solver import BatchedMPC  # noqa: F401
 from .mpc import Controller, Simulator, Track, VehicleModel, closed_loop  # noqa: F401
 from .scenarios import X0_REFERENCE, sample_x0  # noqa: F401
+from .velocity import Vehicle, VehicleMX5, VelocityProfile, VpVehicle  # noqa: F401
 from ._build import build as build_library  # noqa: F401

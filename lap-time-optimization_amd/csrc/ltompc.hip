@@ -769,4 +769,41 @@ int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const
   return 0;
 }
 
+int ltompc_velocity_profile(int device, const ltompc_vp_vehicle* veh, int n, int batch, const double* s, const double* k,
+                            const double* s_max, double* v, double* v_local, double* v_acclim, double* v_declim) {
+  if (!veh || !s || !k || !s_max || !v) return fail("ltompc_velocity_profile: null argument");
+  if (n < 2 || batch < 1) return fail("ltompc_velocity_profile: need n >= 2 samples and batch >= 1");
+  if (veh->kind != 0 && veh->kind != 1) return fail("ltompc_velocity_profile: vehicle kind must be 0 (engine map) or 1 (MX-5)");
+  if (veh->kind == 0 && (veh->n_map < 2 || veh->n_map > 16)) return fail("ltompc_velocity_profile: engine map needs 2 .. 16 points");
+  if (!(veh->mass > 0)) return fail("ltompc_velocity_profile: mass must be positive");
+  for (size_t i = 0; i < (size_t)n * batch; i++)
+    if (!(k[i] >= 0.0) || !std::isfinite(s[i])) return fail("ltompc_velocity_profile: curvature must be >= 0 and s finite");
+  int ndev = 0;
+  HIPCHECK(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("ltompc_velocity_profile: no such HIP device");
+  HIPCHECK(hipSetDevice(device));
+  const size_t nb = sizeof(double) * (size_t)n * batch;
+  double *d_s = nullptr, *d_k = nullptr, *d_m = nullptr, *d_out = nullptr;
+  hipError_t e = hipMalloc((void**)&d_s, nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_k, nb);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_m, sizeof(double) * batch);
+  if (e == hipSuccess) e = hipMalloc((void**)&d_out, 4 * nb);
+  if (e == hipSuccess) e = hipMemcpy(d_s, s, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_k, k, nb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_m, s_max, sizeof(double) * batch, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const size_t nn = (size_t)n * batch;
+    hipLaunchKernelGGL(k_velocity_profile, dim3((batch + 63) / 64), dim3(64), 0, 0, *veh, n, batch, d_s, d_k, d_m, d_out, d_out + nn, d_out + 2 * nn, d_out + 3 * nn);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(v, d_out, nb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && v_local) e = hipMemcpy(v_local, d_out + nn, nb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && v_acclim) e = hipMemcpy(v_acclim, d_out + 2 * nn, nb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && v_declim) e = hipMemcpy(v_declim, d_out + 3 * nn, nb, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(d_s), (void)hipFree(d_k), (void)hipFree(d_m), (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(std::string("ltompc_velocity_profile: ") + hipGetErrorString(e));
+  return 0;
+}
+
 }  // extern "C"

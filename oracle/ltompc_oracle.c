@@ -1581,6 +1581,82 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
   }
   return 0;
 }
+/* ------------------------------------------------------------------ velocity-profile generator
+ * Restates src/velocity.py:14-76 with src/vehicle.py:24-35 / src/vehicleMX5.py:19-38 the way the reference writes it:
+ * explicit rolled (and flipped) copies of s, k, v starting at the slowest point, python's negative index v[i-1] for i = 0.
+ * (The HIP kernel does the index arithmetic on the fly instead: two implementations, one fixture.) */
+static double vp_engine(const ltompc_vp_vehicle* V, double v) {
+  if (V->kind == 1) return (V->T * V->C_m) - V->Cr_0 - (V->Cr_2 * (v * v));
+  int n = V->n_map;
+  if (v <= V->map_v[0]) return V->map_f[0];
+  if (v >= V->map_v[n - 1]) return V->map_f[n - 1];
+  int j = 0;
+  while (j + 2 < n && v >= V->map_v[j + 1]) j++;
+  double slope = (V->map_f[j + 1] - V->map_f[j]) / (V->map_v[j + 1] - V->map_v[j]);
+  return slope * (v - V->map_v[j]) + V->map_f[j];
+}
+static double vp_tract(const ltompc_vp_vehicle* V, double v, double k) {
+  const double GRAV = 9.81;
+  double f, f_lat;
+  if (V->kind == 1) {
+    double Fn = V->mass * GRAV;
+    f = V->lam * V->D * Fn;
+    f_lat = V->mass * v * v * k;
+  } else {
+    f = V->friction_coef * V->mass * GRAV;
+    f_lat = V->mass * (v * v) * k;
+  }
+  if (f <= f_lat) return 0.0;
+  return sqrt(f * f - f_lat * f_lat);
+}
+int oracle_velocity_profile(const ltompc_vp_vehicle* V, int n, int batch, const double* s_all, const double* k_all, const double* s_max_all,
+                            double* v_all, double* vloc_all, double* vacc_all, double* vdec_all) {
+  const double GRAV = 9.81;
+  double *s = malloc(sizeof(double) * 3 * (size_t)n), *k = s + n, *v = k + n;
+  for (int b = 0; b < batch; b++) {
+    const double *so = s_all + (size_t)b * n, *ko = k_all + (size_t)b * n;
+    double *vloc = vloc_all + (size_t)b * n, *vacc = vacc_all + (size_t)b * n, *vdec = vdec_all + (size_t)b * n;
+    const double s_max = s_max_all[b];
+    const int closed = s_max >= 0.0;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+      vloc[i] = sqrt(V->friction_coef * GRAV / ko[i]);
+      if (vloc[i] < vloc[m]) m = i;
+    }
+    /* limit_acceleration: np.roll(a, -m)[j] = a[(j + m) % n] */
+    for (int j = 0; j < n; j++) s[j] = so[(j + m) % n], k[j] = ko[(j + m) % n], v[j] = vloc[(j + m) % n];
+    for (int i = 0; i < n; i++) {
+      int wrap = i == ((n - m) % n), im = i ? i - 1 : n - 1;
+      if (wrap && !closed) continue;
+      if (v[i] > v[im]) {
+        double traction = vp_tract(V, v[im], k[im]), eng = vp_engine(V, v[im]);
+        double force = eng < traction ? eng : traction;
+        double accel = force / V->mass;
+        double ds = wrap ? s_max - s[im] : s[i] - s[im];
+        double vlim = sqrt(v[im] * v[im] + 2 * accel * ds);
+        v[i] = v[i] < vlim ? v[i] : vlim;
+      }
+    }
+    for (int j = 0; j < n; j++) vacc[(j + m) % n] = v[j];
+    /* limit_deceleration: flip(roll(a, -m))[j] = a[(n - 1 - j + m) % n] */
+    for (int j = 0; j < n; j++) s[j] = so[(n - 1 - j + m) % n], k[j] = ko[(n - 1 - j + m) % n], v[j] = vloc[(n - 1 - j + m) % n];
+    for (int i = 0; i < n; i++) {
+      int wrap = i == m, im = i ? i - 1 : n - 1;
+      if (wrap && !closed) continue;
+      if (v[i] > v[im]) {
+        double decel = vp_tract(V, v[im], k[im]) / V->mass;
+        double ds = wrap ? s_max - s[i] : s[im] - s[i];
+        double vlim = sqrt(v[im] * v[im] + 2 * decel * ds);
+        v[i] = v[i] < vlim ? v[i] : vlim;
+      }
+    }
+    for (int j = 0; j < n; j++) vdec[(n - 1 - j + m) % n] = v[j];
+    for (int i = 0; i < n; i++) v_all[(size_t)b * n + i] = vacc[i] < vdec[i] ? vacc[i] : vdec[i];
+  }
+  free(s);
+  return 0;
+}
+
 int oracle_num_ineq(const ltompc_params* p) {
   bounds_t bd;
   build_bounds(p, &bd);

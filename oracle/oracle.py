@@ -149,5 +149,21 @@ class Oracle:
                     n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9])
 
 
+class VpVehicle(C.Structure):
+    """ltompc_vp_vehicle (include/ltompc.h)."""
+    _fields_ = [("kind", C.c_int), ("n_map", C.c_int), ("mass", C.c_double), ("friction_coef", C.c_double), ("lam", C.c_double),
+                ("D", C.c_double), ("T", C.c_double), ("C_m", C.c_double), ("Cr_0", C.c_double), ("Cr_2", C.c_double),
+                ("map_v", C.c_double * 16), ("map_f", C.c_double * 16)]
+
+
+def velocity_profile(veh: VpVehicle, S, K, s_max):
+    """CPU restatement of src/velocity.py:14-76 for a batch of profiles: (v, v_local, v_acclim, v_declim), each (B, n)."""
+    S, K = np.ascontiguousarray(np.atleast_2d(S), float), np.ascontiguousarray(np.atleast_2d(K), float)
+    sm = np.ascontiguousarray(s_max, float)
+    out = [np.empty_like(S) for _ in range(4)]
+    lib().oracle_velocity_profile(C.byref(veh), S.shape[1], S.shape[0], _p(S), _p(K), _p(sm), *(_p(a) for a in out))
+    return tuple(out)
+
+
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
