@@ -116,6 +116,7 @@ struct Consts {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); \
   } while (0)
 
+#if !defined(LTOMPC_HOST_HARNESS)  // (the harness brings its own: 8 OS threads and a barrier, hip_shim.h)
 __device__ __forceinline__ double grp_max(double v) {  // over the 8 lanes of an instance (lane stride 8)
   v = fmax(v, __shfl_xor(v, 8)), v = fmax(v, __shfl_xor(v, 16)), v = fmax(v, __shfl_xor(v, 32));
   return v;
@@ -128,5 +129,11 @@ __device__ __forceinline__ double grp_min(double v) {
   v = fmin(v, __shfl_xor(v, 8)), v = fmin(v, __shfl_xor(v, 16)), v = fmin(v, __shfl_xor(v, 32));
   return v;
 }
+
+#else
+using ::grp_max;
+using ::grp_min;
+using ::grp_sum;
+#endif
 
 }  // namespace ltompc

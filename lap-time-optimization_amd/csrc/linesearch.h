@@ -66,16 +66,18 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
     double sl = 0.0, pr = 1.0;
     double tt[BP::fixed ? MAX_NI : 1];  // compile-time bound pattern: the slacks of the candidate in one batch of loads
     if (BP::fixed) {
-      double t0[MAX_NI], d0[MAX_NI];
+      double t0[MAX_NI] = {}, d0[MAX_NI] = {};  // (zero: the pinning below touches whole chunks of 8)
       const int nb = for_each_bound<BP>(K.p, [&](int mm, int, int, double, double) { t0[mm] = PL(W.T, mm, k, N), d0[mm] = PL(W.dT, mm, k, N); });
       // (all of them in registers before the first use: left alone the compiler issues and awaits them pair by pair)
 #pragma unroll
       for (int q = 0; q < MAX_NI; q += 8)
         if (PIN && q < nb) {  // (k_step1, two wavefronts per SIMD, is faster without: fewer registers)
+#if defined(__HIP_DEVICE_COMPILE__)
           double* a = t0 + q;
           double* c = d0 + q;
           asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
                             "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]), "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+#endif
         }
 #pragma unroll
       for (int q = 0; q < MAX_NI; q++)

@@ -317,8 +317,9 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp, true), rc |= h->dalloc(&W.dC, 8 * N * Bp, true), rc |= h->dalloc(&W.dU, 2 * N * Bp, true);
   rc |= h->dalloc(&W.nL1, 8 * N * Bp, true), rc |= h->dalloc(&W.nL2, 8 * N * Bp, true);
   rc |= h->dalloc(&W.dT, (ni + NNL) * N * Bp, true), rc |= h->dalloc(&W.dNU, ni * N * Bp, true);
-  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp + 64, true), rc |=  // (+64: k_riccati8 fetches one field past the last block)
-  h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp, true);
+  // (k_riccati8's staging fetches one field past each STAGE block, k <= N - 1: that word is the first of the next block, and
+  //  block N, the terminal node, follows the last stage block; no padding needed)
+  rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp, true), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp, true);
   rc |= h->dalloc(&W.RS, (size_t)RS_NF * N * Bp, true), rc |= h->dalloc(&W.SP, (size_t)SP_NF * N * Bp, true);
   rc |= h->dalloc(&W.LS, (size_t)3 * (options->n_linesearch + 1) * N * Bp, true);
   rc |= h->dalloc(&W.x0, 8 * Bp), rc |= h->dalloc(&W.uprev, 2 * Bp);

@@ -13,7 +13,11 @@
 // Everything is fp64.  The CPU oracle (oracle/ltompc_oracle.c) obtains the same derivatives by generic
 // second-order forward AD; the two implementations are compared in tests/, neither includes the other.
 #pragma once
+#if defined(LTOMPC_HOST_HARNESS)  // tests/host_harness: the device functions as host C++ under ASan / UBSan (test infrastructure)
+#include "hip_shim.h"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include "../../include/ltompc.h"
 

@@ -994,7 +994,11 @@ __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, Launch la, in
 // One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
 // sweep, and 8 instances per wavefront make that sweep ~3x longer than it has to be).  Dynamic LDS: ric1_lds_bytes(N).
 __global__ void __launch_bounds__(64) k_riccati1(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
+#if defined(LTOMPC_HOST_HARNESS)
+  static double lds1[1];  // (never run by the harness)
+#else
   extern __shared__ double lds1[];
+#endif
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   if ((int)blockIdx.x >= la.nact[0]) return;
   const int N = W.N;

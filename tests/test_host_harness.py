@@ -1,0 +1,81 @@
+"""The solver's device code as host C++ under AddressSanitizer + UndefinedBehaviorSanitizer (tests/host_harness):
+the thread-per-slot kernels (k_init, k_eval, k_expand, k_linesearch, k_pick, k_update, k_plant, ...) and the serial Riccati
+kernel run whole interior-point solves on the CPU with every work buffer NaN-poisoned and allocated at its exact size; any
+out-of-bounds access or undefined operation aborts the run, a read of a never-written word shows up as a NaN result.
+The numbers are compared with the oracle (the GPU library's own results are compared with the oracle in test_gpu_parity.py).
+Test infrastructure only: the package never builds or loads this."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HARNESS_DIR = os.path.join(ROOT, "tests", "host_harness")
+CSRC = os.path.join(ROOT, "lap-time-optimization_amd", "csrc")
+EXE = os.path.join(HARNESS_DIR, "harness")
+
+
+@pytest.fixture(scope="module")
+def harness():
+    srcs = [os.path.join(HARNESS_DIR, f) for f in ("harness.cpp", "hip_shim.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    srcs.append(os.path.join(ROOT, "include", "ltompc.h"))
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-DLTOMPC_HOST_HARNESS",
+                               "-I", CSRC, "-I", HARNESS_DIR, os.path.join(HARNESS_DIR, "harness.cpp"), "-o", EXE, "-lpthread"])
+    return EXE
+
+
+def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2):
+    prob = tmp_path / "problem.txt"
+    tab = tables.packed()
+    with open(prob, "w") as f:
+        f.write(f"{tab.shape[1]} {N} {x0.shape[0]} {any_bounds} {soft_rho!r} {ticks}\n")
+        np.savetxt(f, tab.ravel()[None], fmt="%.17g")
+        np.savetxt(f, x0.ravel()[None], fmt="%.17g")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([exe, str(prob)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]   # a sanitizer report ends the process with a non-zero code
+    assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
+    res, cur = [], None
+    for line in out.stdout.splitlines():
+        if line.startswith("tick"):
+            cur = []; res.append(cur)
+        else:
+            cur.append([float(v) for v in line.split()])
+    return [np.array(r) for r in res]
+
+
+@pytest.mark.parametrize("any_bounds", [0, 1])
+def test_device_code_is_sanitizer_clean_and_matches_the_oracle(harness, tmp_path, oracle, pkg, tables, any_bounds):
+    """Two closed-loop ticks of a small batch (cold start + warm start through k_plant), N = 8: ASan / UBSan silent, no NaN
+    from the poisoned buffers, statuses and controls as the oracle's.  The batch holds the reference's x0, sampled states, a
+    state that needs the restoration phase and one that is off the track (INFEASIBLE)."""
+    N = 8
+    x0 = np.vstack([pkg.X0_REFERENCE[None], pkg.sample_x0(tables, 5, seed=61),
+                    [[226.623754, -0.545036120, -0.0112268024, 8.52329373, 0.122918012, 0.161888169, 0.0837443810, 0.371730909]],
+                    [[100.0, 4.0, 0.0, 10.0, 0, 0, 0, 0]]])
+    res = _run(harness, tmp_path, tables, x0, N, any_bounds=any_bounds)
+    x, ref, up = x0, None, np.zeros((len(x0), 2))
+    for tick, r in enumerate(res):
+        ref = oracle.solve(x, N, up, ref, nthreads=4, prev_status=None if ref is None else ref["status"])
+        assert np.all(np.isfinite(r)), tick
+        assert np.array_equal(r[:, 1].astype(int), ref["status"]), (tick, r[:, 1], ref["status"])
+        both = ref["status"] == 0
+        assert both.sum() >= 6 and np.abs(r[:, 3:5] - ref["u0"])[both].max() < 1e-6, tick
+        assert (np.abs(r[:, 2] - ref["iters"])[both] <= 2).all(), tick
+        # the harness continues from its own controls (k_plant, 100 sub-steps)
+        x, up = oracle.plant_step(x, r[:, 3:5], n_sub=100), r[:, 3:5]
+    assert len(res) == 2
+
+
+def test_device_code_soft_constraints_under_sanitizers(harness, tmp_path, orc, pkg, tables):
+    """The elastic planes (options.soft_rho) on the same harness."""
+    N = 6
+    x0 = pkg.sample_x0(tables, 4, seed=62)
+    res = _run(harness, tmp_path, tables, x0, N, soft_rho=100.0, ticks=1)
+    o = orc.default_options(); o.soft_rho = 100.0
+    ref = orc.Oracle(tables.packed(), options=o).solve(x0, N, nthreads=4)
+    assert np.all(np.isfinite(res[0])) and np.array_equal(res[0][:, 1].astype(int), ref["status"])
+    assert np.abs(res[0][:, 3:5] - ref["u0"]).max() < 1e-6
