@@ -62,6 +62,13 @@ typedef struct ltompc_params {
   /* controller.py:79-103 (LTOMPC_NO_BOUND where the reference sets nothing) */
   double x_lb[LTOMPC_NX], x_ub[LTOMPC_NX];
   double u_lb[LTOMPC_NU], u_ub[LTOMPC_NU];
+  /* Friction-ellipse constraints of the two axles (model.py:86-99 get_traction_ellipse_constraint; their registration as
+   * soft nl constraints is commented out in the reference, controller.py:72-74: ell_penalty = 0 is the reference).
+   *   long = ell_rho 0.5 C_m T ;  g_a = (long^2 + F_y,a^2) / ell_D_a^2 - 1 <= 0 at the nodes 1 .. N-1, a = front, rear,
+   * always with an elastic variable that costs ell_penalty (do_mpc: soft_constraint=True, penalty_term_cons).  With
+   * ell_D_f = ell_D_r = 1.0 (= alpha D with the reference's alpha = 1 and D = 1.0) and ell_rho = 1 this is the reference's
+   * expression, which no tyre force in newtons can satisfy; a physical radius is the peak lateral force F_N D. */
+  double ell_penalty, ell_rho, ell_D_f, ell_D_r;
 } ltompc_params;
 
 /* NLP transcription + interior-point options.  Defaults follow do_mpc 4.6.5 / IPOPT 3.14 defaults

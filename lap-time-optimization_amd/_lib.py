@@ -19,7 +19,8 @@ class Params(C.Structure):
         "mass", "inertia_z", "length_f", "length_r", "width", "B_f", "C_f", "D_f", "B_r", "C_r", "D_r",
         "C_m", "Cr_0", "Cr_2", "gravity", "ptv", "q_n", "q_mu", "q_vy", "q_v", "vref_scale", "q_B")] + [
         ("r_du", C.c_double * 2), ("x_lb", C.c_double * 8), ("x_ub", C.c_double * 8),
-        ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2)]
+        ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2)] + [
+        (n, C.c_double) for n in ("ell_penalty", "ell_rho", "ell_D_f", "ell_D_r")]
 
 
 class Options(C.Structure):

@@ -37,7 +37,9 @@
 #define NH 36
 #define MAXXB 16
 #define NNL 3 /* gL, gR+ , gR- : see cons_jet */
-#define MAXI (4 + 2 * MAXXB + NNL)
+#define NEL 2 /* friction-ellipse constraints of the two axles (model.py:86-99), present when params.ell_penalty > 0 */
+#define NNLT (NNL + NEL)
+#define MAXI (4 + 2 * MAXXB + NNLT)
 
 /* ------------------------------------------------------------------ jets */
 typedef struct {
@@ -320,6 +322,32 @@ static void cons_val(const ltompc_params* p, const tables_t* T, const double* x,
   g[2] = -x[1] - sp + cw - NR;
 }
 
+/* Friction-ellipse constraints of the two axles (model.py:86-99 get_traction_ellipse_constraint; registered as SOFT nl
+ * constraints in lines the reference has commented out, controller.py:72-74):
+ *   long = rho 0.5 C_m T ,  ellipse_a = long^2 + F_y,a^2 - (alpha D_a)^2 <= 0 ,  a = front, rear.
+ * Here normalised by the radius, g_a = (long^2 + F_y,a^2) / D_a^2 - 1 with D_a = params.ell_D_f / ell_D_r (= alpha D_a; with the
+ * reference's D = 1.0 this IS its expression; a physical radius is F_N D), rho = params.ell_rho.  Always soft: elastic
+ * variable with penalty params.ell_penalty (do_mpc: penalty_term_cons). */
+static void ell_jet(const ltompc_params* p, const double* x, jet* g) {
+  jet vx = jvar(x[3], 3), vy = jvar(x[4], 4), r = jvar(x[5], 5), de = jvar(x[6], 6), th = jvar(x[7], 7);
+  jet Fyf, Fyr;
+  slip_forces_jet(p, vx, vy, r, de, &Fyf, &Fyr, NULL, NULL);
+  jet lng = jscale(th, p->ell_rho * 0.5 * p->C_m);
+  jet l2 = jmul(lng, lng);
+  g[0] = jadds(jscale(jadd(l2, jmul(Fyf, Fyf)), 1.0 / (p->ell_D_f * p->ell_D_f)), -1.0);
+  g[1] = jadds(jscale(jadd(l2, jmul(Fyr, Fyr)), 1.0 / (p->ell_D_r * p->ell_D_r)), -1.0);
+}
+static void ell_val(const ltompc_params* p, const double* x, double* g) {
+  double vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
+  double af = atan2(vy + p->length_f * r, vx) - de, ar = atan2(vy - p->length_r * r, vx);
+  double L = p->length_f + p->length_r;
+  double Fnf = p->length_r * p->mass * p->gravity / L, Fnr = p->length_f * p->mass * p->gravity / L;
+  double Fyf = -Fnf * p->D_f * sin(p->C_f * atan(p->B_f * af)), Fyr = -Fnr * p->D_r * sin(p->C_r * atan(p->B_r * ar));
+  double lng = p->ell_rho * 0.5 * p->C_m * th;
+  g[0] = (lng * lng + Fyf * Fyf) / (p->ell_D_f * p->ell_D_f) - 1.0;
+  g[1] = (lng * lng + Fyr * Fyr) / (p->ell_D_r * p->ell_D_r) - 1.0;
+}
+
 /* ------------------------------------------------------------------ small dense LA */
 /* LU with partial pivoting, n <= 16, row-major a[n*n]; returns 0 ok */
 static int lu_factor(double* a, int n, int* piv) {
@@ -385,7 +413,9 @@ typedef struct {
   int n_ub;
   int ub_idx[4];
   double ub_sgn[4], ub_val[4];
-  int ni; /* inequalities per slot = n_ub + 2 n_xb + NNL */
+  int nel; /* 0, or NEL when the friction-ellipse constraints are switched on */
+  int nnl; /* nonlinear constraints per node = NNL + nel */
+  int ni;  /* inequalities per slot = n_ub + 2 n_xb + nnl */
 } bounds_t;
 
 static void build_bounds(const ltompc_params* p, bounds_t* b) {
@@ -411,7 +441,9 @@ static void build_bounds(const ltompc_params* p, bounds_t* b) {
       b->n_ub++;
     }
   }
-  b->ni = b->n_ub + 2 * b->n_xb + NNL;
+  b->nel = p->ell_penalty > 0 ? NEL : 0;
+  b->nnl = NNL + b->nel;
+  b->ni = b->n_ub + 2 * b->n_xb + b->nnl;
 }
 static inline double bound_h(double sgn, double val, double x) { return sgn < 0 ? val - x : x - val; }
 
@@ -421,9 +453,15 @@ typedef struct {
   int N;
   double *x, *c, *u, *l1, *l2; /* (N+1)*8, N*8, N*2, N*8, N*8 */
   double *t, *nu;              /* N*MAXI */
-  double *e;                   /* N*NNL: elastic variables of the softened track constraints (soft_rho > 0) */
-  double rho;
+  double *e;                   /* N*NNLT: elastic variables of the softened nonlinear constraints */
+  double rho;                  /* penalty of the track constraints' elastic variables (0: hard) */
+  double pen[NNLT];            /* penalty per nonlinear constraint: rho x 3, params.ell_penalty x 2 (it_set_rho) */
 } iterate_t;
+static void it_set_rho(iterate_t* it, double rho, const ltompc_params* p) {
+  it->rho = rho;
+  for (int q = 0; q < NNL; q++) it->pen[q] = rho;
+  for (int q = NNL; q < NNLT; q++) it->pen[q] = p->ell_penalty;
+}
 
 static iterate_t it_alloc(int N) {
   iterate_t it;
@@ -435,8 +473,9 @@ static iterate_t it_alloc(int N) {
   it.l2 = calloc((size_t)N * NX, sizeof(double));
   it.t = calloc((size_t)N * MAXI, sizeof(double));
   it.nu = calloc((size_t)N * MAXI, sizeof(double));
-  it.e = calloc((size_t)N * NNL, sizeof(double));
+  it.e = calloc((size_t)N * NNLT, sizeof(double));
   it.rho = 0;
+  memset(it.pen, 0, sizeof it.pen);
   return it;
 }
 static void it_free(iterate_t* it) {
@@ -446,15 +485,18 @@ static void it_free(iterate_t* it) {
 /* inequality values of slot k (u_k, c_k, x_{k+1}); order: u bounds, c bounds, x+ bounds, gL, gR.
  * nl constraints exist at nodes 1..N-1 only (node 0 is fixed data, node N is not checked by do_mpc). */
 static void slot_ineq(const ltompc_params* p, const tables_t* T, const bounds_t* bd, int N, int k,
-                      const double* u, const double* c, const double* xp, const double* e, double* h, int* active) {
+                      const double* u, const double* c, const double* xp, const double* e, const double* pen, double* h, int* active) {
   int m = 0;
   for (int i = 0; i < bd->n_ub; i++, m++) h[m] = bound_h(bd->ub_sgn[i], bd->ub_val[i], u[bd->ub_idx[i]]), active[m] = 1;
   for (int i = 0; i < bd->n_xb; i++, m++) h[m] = bound_h(bd->xb_sgn[i], bd->xb_val[i], c[bd->xb_idx[i]]), active[m] = 1;
   for (int i = 0; i < bd->n_xb; i++, m++) h[m] = bound_h(bd->xb_sgn[i], bd->xb_val[i], xp[bd->xb_idx[i]]), active[m] = 1;
   int nl = (k + 1 <= N - 1);
-  double g[NNL] = {-1, -1, -1};
-  if (nl) cons_val(p, T, xp, g);
-  for (int q = 0; q < NNL; q++) h[m] = g[q] - (e && nl ? e[q] : 0.0), active[m++] = nl; /* soft: h = g - e */
+  double g[NNLT] = {-1, -1, -1, -1, -1};
+  if (nl) {
+    cons_val(p, T, xp, g);
+    if (bd->nel) ell_val(p, xp, g + NNL);
+  }
+  for (int q = 0; q < bd->nnl; q++) h[m] = g[q] - (e && nl && pen[q] > 0 ? e[q] : 0.0), active[m++] = nl; /* soft: h = g - e */
 }
 
 /* constraint residuals of an iterate: collocation equations G1, G2 (N x 8 each) and inequality rows r = h + t
@@ -482,7 +524,7 @@ static void eval_residuals(const ltompc_params* p, const ltompc_options* o, cons
     for (int i = 0; i < NU; i++) co += p->r_du[i] * (u[i] - v[i]) * (u[i] - v[i]);
     double h[MAXI];
     int act[MAXI];
-    slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, h, act);
+    slot_ineq(p, T, bd, N, k, u, c, xp, it->e + k * NNLT, it->pen, h, act);
     for (int m = 0; m < bd->ni; m++) {
       if (R) R[k * MAXI + m] = 0.0;
       if (act[m]) {
@@ -490,9 +532,10 @@ static void eval_residuals(const ltompc_params* p, const ltompc_options* o, cons
         th += fabs(h[m] + t);
         if (R) R[k * MAXI + m] = h[m] + t;
         sl += log(t);
-        if (it->rho > 0 && m >= bd->ni - NNL) {
-          double e = it->e[k * NNL + m - (bd->ni - NNL)];
-          sl += log(e), co += it->rho * e;
+        const int q = m - (bd->ni - bd->nnl);
+        if (q >= 0 && it->pen[q] > 0) {
+          double e = it->e[k * NNLT + q];
+          sl += log(e), co += it->pen[q] * e;
         }
       }
     }
@@ -508,7 +551,7 @@ typedef struct {
   double Du[2], gub[2];     /* u_k: diagonal barrier Hessian and barrier gradient               */
   double dc_dual[8], dxp_dual[8], du_dual[2]; /* parts of grad_z Lagrangian not involving lambda */
   double gcost[8];          /* grad of node cost at x_{k+1}                                     */
-  double gnl[NNL][8];       /* grad of gL, gR+, gR- at x_{k+1}                                        */
+  double gnl[NNLT][8];      /* grad of gL, gR+, gR- (and the two ellipse constraints) at x_{k+1}       */
   double h[MAXI];
   int act[MAXI];
   double cost;
@@ -530,11 +573,11 @@ static void slot_gradients(const bounds_t* bd, const iterate_t* it, int k, doubl
   for (int i = 0; i < bd->n_xb; i++, m++) L->gc[bd->xb_idx[i]] += bd->xb_sgn[i] * ((mu + nu[m] * L->rI[m]) / t[m]);
   for (int i = 0; i < bd->n_xb; i++, m++) L->gxp[bd->xb_idx[i]] += bd->xb_sgn[i] * ((mu + nu[m] * L->rI[m]) / t[m]);
   if (L->act[m])
-    for (int q = 0; q < NNL; q++) {
+    for (int q = 0; q < bd->nnl; q++) {
       int mm = m + q;
       double sg = (mu + nu[mm] * L->rI[mm]) / t[mm];
-      if (it->rho > 0) {
-        double e = it->e[k * NNL + q], z = it->rho - nu[mm];
+      if (it->pen[q] > 0) {
+        double e = it->e[k * NNLT + q], z = it->pen[q] - nu[mm];
         double Sg = 1.0 / (t[mm] / nu[mm] + e / z);
         /* (geff from the SAME numbers the step recovery uses: a difference of one ulp of the O(1) terms of g is
          *  amplified by Sg ~ nu / t ~ 1e9 into the dual residual) */
@@ -580,7 +623,7 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
     for (int b = 0; b < NX; b++) L->Hxp[a * 8 + b] += cj.h[hidx(a, b)];
   }
   L->Du[0] = L->Du[1] = 0, L->du_dual[0] = L->du_dual[1] = 0;
-  slot_ineq(p, T, bd, N, k, u, c, xp, it->rho > 0 ? it->e + k * NNL : NULL, L->h, L->act);
+  slot_ineq(p, T, bd, N, k, u, c, xp, it->e + k * NNLT, it->pen, L->h, L->act);
   for (int m = 0; m < bd->ni; m++) L->rI[m] = L->act[m] ? L->h[m] + t[m] : 0.0;
   /* barrier contributions to the Hessian: Sigma = nu/t */
   int m = 0;
@@ -598,13 +641,14 @@ static void linearise_slot(const ltompc_params* p, const ltompc_options* o, cons
   }
   memset(L->gnl, 0, sizeof L->gnl);
   if (L->act[m]) {
-    jet g[NNL];
+    jet g[NNLT];
     cons_jet(p, T, xp, g);
-    for (int q = 0; q < NNL; q++) {
+    if (bd->nel) ell_jet(p, xp, g + NNL);
+    for (int q = 0; q < bd->nnl; q++) {
       int mm = m + q;
       double Sg = nu[mm] / t[mm];
-      if (it->rho > 0) { /* softened: g - e + t = 0, e >= 0 with multiplier z = rho - nu */
-        double e = it->e[k * NNL + q], z = it->rho - nu[mm];
+      if (it->pen[q] > 0) { /* softened: g - e + t = 0, e >= 0 with multiplier z = rho - nu */
+        double e = it->e[k * NNLT + q], z = it->pen[q] - nu[mm];
         Sg = 1.0 / (t[mm] / nu[mm] + e / z);
       }
       for (int a = 0; a < NX; a++) {
@@ -897,7 +941,7 @@ static void slack_steps(ipws* s, double tau, double* a_pri_out, double* a_dua_ou
   const ltompc_params* p = s->p;
   iterate_t* it = &s->it;
   slot_lin* L = s->L;
-  const double mu = s->mu, rho = it->rho;
+  const double mu = s->mu;
   double *dx = s->dx, *dc = s->dc, *du = s->du, *dt = s->dt, *dnu = s->dnu, *de = s->de;
   double a_pri = 1.0, a_dua = 1.0, gphi_d = 0.0;
   for (int k = 0; k < N; k++) {
@@ -912,7 +956,7 @@ static void slack_steps(ipws* s, double tau, double* a_pri_out, double* a_dua_ou
     for (int i = 0; i < ni; i++, m++) {
       if (!L[k].act[m]) {
         dt[k * MAXI + m] = dnu[k * MAXI + m] = 0;
-        if (m >= ni - NNL) de[k * NNL + m - (ni - NNL)] = 0;
+        if (m >= ni - bd->nnl) de[k * NNLT + m - (ni - bd->nnl)] = 0;
         continue;
       }
       double gd;
@@ -927,14 +971,16 @@ static void slack_steps(ipws* s, double tau, double* a_pri_out, double* a_dua_ou
       double t = it->t[k * MAXI + m], nu = it->nu[k * MAXI + m];
       double dtt = -L[k].rI[m] - gd;
       double dn = (mu - nu * dtt) / t - nu;
-      if (rho > 0 && m >= ni - NNL) {
-        int q = m - (ni - NNL);
-        double e = it->e[k * NNL + q], z = rho - nu;
+      const int q = m - (ni - bd->nnl);
+      if (q >= 0) de[k * NNLT + q] = 0;
+      if (q >= 0 && it->pen[q] > 0) {
+        const double rho = it->pen[q];
+        double e = it->e[k * NNLT + q], z = rho - nu;
         double Sg = 1.0 / (t / nu + e / z);
         dn = Sg * (gd + (L[k].rI[m] + e - t) + mu / nu - mu / z);
         dtt = mu / nu - t - (t / nu) * dn;
         double dee = mu / z - e + (e / z) * dn;
-        de[k * NNL + q] = dee;
+        de[k * NNLT + q] = dee;
         if (dee < 0) a_pri = fmin(a_pri, -tau * e / dee);
         if (dn > 0) a_dua = fmin(a_dua, tau * z / dn);
         gphi_d += rho * dee - mu * dee / e;
@@ -959,7 +1005,7 @@ static void make_trial(ipws* s, double alpha) {
     for (int i = 0; i < NX; i++) tr->c[k * NX + i] = it->c[k * NX + i] + alpha * s->dc[k * NX + i];
     for (int i = 0; i < NU; i++) tr->u[k * NU + i] = it->u[k * NU + i] + alpha * s->du[k * NU + i];
     for (int m = 0; m < ni; m++) tr->t[k * MAXI + m] = it->t[k * MAXI + m] + alpha * s->dt[k * MAXI + m];
-    for (int q = 0; q < NNL; q++) tr->e[k * NNL + q] = it->e[k * NNL + q] + alpha * s->de[k * NNL + q];
+    for (int q = 0; q < NNLT; q++) tr->e[k * NNLT + q] = it->e[k * NNLT + q] + alpha * s->de[k * NNLT + q];
   }
 }
 
@@ -969,25 +1015,29 @@ static void init_slacks(ipws* s) {
   const int N = s->N, ni = s->ni;
   iterate_t* it = &s->it;
   const ltompc_options* o = s->o;
-  const double mu = s->mu, rho = it->rho;
+  const double mu = s->mu;
+  const int nnl = s->bd.nnl;
   for (int k = 0; k < N; k++) {
     double h[MAXI];
     int act[MAXI];
-    slot_ineq(s->p, s->T, &s->bd, N, k, it->u + k * NU, it->c + k * NX, it->x + (k + 1) * NX, NULL, h, act);
+    slot_ineq(s->p, s->T, &s->bd, N, k, it->u + k * NU, it->c + k * NX, it->x + (k + 1) * NX, NULL, it->pen, h, act);
     for (int m = 0; m < ni; m++) {
-      if (rho > 0 && m >= ni - NNL) {
+      const int q = m - (ni - nnl);
+      if (q >= 0) it->e[k * NNLT + q] = 0.0;
+      if (q >= 0 && it->pen[q] > 0) {
+        const double rho = it->pen[q];
         /* softened track constraint: slack and multiplier as for the hard one (t = max(-g, bound_push), nu = mu / t,
          * so that a violated constraint starts as an INFEASIBILITY of g - e + t = 0 that the Newton steps remove, not
          * as a large elastic variable with nu ~ rho that the barrier lets go of only slowly), the elastic variable
          * on the central path of its own pair: e (rho - nu) = mu.  t >= 2 mu / rho keeps nu <= rho / 2. */
         double t = fmax(fmax(-h[m], o->bound_push), 2 * mu / rho), nu = mu / t;
-        it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu, it->e[k * NNL + m - (ni - NNL)] = mu / (rho - nu);
+        it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu, it->e[k * NNLT + q] = mu / (rho - nu);
         if (h[m] > ELASTIC_CP_VIOL) {
           /* grossly violated (here the Newton steps would have to shrink t by rho / nu ~ 1e4 at 1 % of a step per
            * iteration): on the central path of the elastic pair instead, e - t = g, t nu = mu, e (rho - nu) = mu */
           double g = h[m], bq = rho * g - 2 * mu;
           t = (-bq + sqrt(bq * bq + 4 * rho * mu * g)) / (2 * rho);
-          it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = mu / t, it->e[k * NNL + m - (ni - NNL)] = g + t;
+          it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = mu / t, it->e[k * NNLT + q] = g + t;
         }
         continue;
       }
@@ -1019,8 +1069,8 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   Tl.eps_mu = 0.0;
   s->it = it_alloc(N), s->tr = it_alloc(N);
   iterate_t *it = &s->it, *tr = &s->tr;
-  it->rho = tr->rho = o->soft_rho;
-  s->de = calloc((size_t)N * NNL, sizeof(double));
+  it_set_rho(it, o->soft_rho, p), it_set_rho(tr, o->soft_rho, p);
+  s->de = calloc((size_t)N * NNLT, sizeof(double));
   s->L = malloc(sizeof(slot_lin) * (size_t)N);
   s->W = malloc(sizeof(stage_ws) * (size_t)N);
   slot_lin* L = s->L;
@@ -1079,14 +1129,13 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   const int resto_allowed = o->resto_rho > 0 && !(o->soft_rho > 0);
   if (start_elastic && resto_allowed && warm) { /* (slacks and elastic variables below: init_slacks with rho = resto_rho) */
     resto = 1, st->n_resto = 1;
-    it->rho = tr->rho = o->resto_rho;
+    it_set_rho(it, o->resto_rho, p), it_set_rho(tr, o->resto_rho, p);
     init_slacks(s);
   }
 
   double eps_next = Tl.eps_s;
   int n_tiny = 0;
   for (iter = 0;; iter++) {
-    double rho = it->rho;
     /* table smoothing follows the barrier parameter with a lag of one iteration (so that one linearisation
      * serves the whole iteration, also when mu is reduced in it); the filter restarts when it changes */
     if (eps_next != Tl.eps_s) Tl.eps_s = eps_next, nfilt = 0, theta0 = -1;
@@ -1101,8 +1150,12 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       const double *l1 = it->l1 + k * NX, *l2 = it->l2 + k * NX;
       const double* v = k ? it->u + (k - 1) * NU : uprev;
       obj += L[k].cost;
-      if (rho > 0 && L[k].act[ni - 1])
-        for (int q = 0; q < NNL; q++) obj += rho * it->e[k * NNL + q], e_max = fmax(e_max, it->e[k * NNL + q]);
+      if (L[k].act[ni - 1])
+        for (int q = 0; q < bd->nnl; q++)
+          if (it->pen[q] > 0) {
+            obj += it->pen[q] * it->e[k * NNLT + q];
+            if (q < NNL) e_max = fmax(e_max, it->e[k * NNLT + q]); /* (the restoration phase is about the track constraints) */
+          }
       for (int a = 0; a < NX; a++) {
         double rcx = L[k].dc_dual[a] + 4.5 * l2[a];
         double rxp = L[k].dxp_dual[a] - 0.5 * l1[a];
@@ -1129,10 +1182,11 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           rc_mu = fmax(rc_mu, fabs(t * nu - mu));
           rc_0 = fmax(rc_0, fabs(t * nu));
           sum_mult += fabs(nu), n_mult++;
-          if (rho > 0 && m >= ni - NNL) {
-            double ez = it->e[k * NNL + m - (ni - NNL)] * (rho - nu);
+          const int q = m - (ni - bd->nnl);
+          if (q >= 0 && it->pen[q] > 0) {
+            double ez = it->e[k * NNLT + q] * (it->pen[q] - nu);
             rc_mu = fmax(rc_mu, fabs(ez - mu)), rc_0 = fmax(rc_0, fabs(ez));
-            sum_mult += fabs(rho - nu), n_mult++;
+            sum_mult += fabs(it->pen[q] - nu), n_mult++;
           }
         }
     }
@@ -1154,7 +1208,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
        * locally: a stationary point of the infeasibility. */
       const double e_tol = term == LTOMPC_STATUS_SOLVED ? o->tol : o->acceptable_tol;
       if (e_max <= e_tol) {
-        resto = 2, it->rho = tr->rho = 0.0;
+        resto = 2, it_set_rho(it, 0.0, p), it_set_rho(tr, 0.0, p);
         n_acc = 0, nfilt = 0, theta0 = -1;
         if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d elastic problem converged, e_max %.2e: back to the hard constraints\n", iter, e_max);
         iter--; /* (this pass only switched the problem: not an iteration) */
@@ -1174,7 +1228,8 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         for (int m = 0; m < ni; m++)
           if (L[k].act[m]) {
             rcm = fmax(rcm, fabs(it->t[k * MAXI + m] * it->nu[k * MAXI + m] - mu));
-            if (rho > 0 && m >= ni - NNL) rcm = fmax(rcm, fabs(it->e[k * NNL + m - (ni - NNL)] * (rho - it->nu[k * MAXI + m]) - mu));
+            const int q = m - (ni - bd->nnl);
+            if (q >= 0 && it->pen[q] > 0) rcm = fmax(rcm, fabs(it->e[k * NNLT + q] * (it->pen[q] - it->nu[k * MAXI + m]) - mu));
           }
       Emu = fmax(Emu, rcm / s_d);
     }
@@ -1353,7 +1408,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
          *      the original problem; here the objective stays, so the elastic problem's solution with e = 0 already
          *      is the solution.) */
         resto = 1, st->n_resto++;
-        it->rho = tr->rho = o->resto_rho;
+        it_set_rho(it, o->resto_rho, p), it_set_rho(tr, o->resto_rho, p);
         memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
         mu = s->mu = o->mu_init;
         Tl.eps_s = eps_next = SMOOTHING(mu);
@@ -1397,7 +1452,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         /* IPOPT eq. (16): keep nu within [mu/(kS t), kS mu/t], kS = 1e10 */
         double lo = mu / (1e10 * t), hi = 1e10 * mu / t;
         it->t[k * MAXI + m] = t, it->nu[k * MAXI + m] = nu < lo ? lo : (nu > hi ? hi : nu);
-        if (rho > 0 && m >= ni - NNL) it->e[k * NNL + m - (ni - NNL)] += alpha * de[k * NNL + m - (ni - NNL)];
+        if (m >= ni - bd->nnl) it->e[k * NNLT + m - (ni - bd->nnl)] += alpha * de[k * NNLT + m - (ni - bd->nnl)];
       }
     }
   }
@@ -1414,7 +1469,7 @@ done:
   st->viol = 0.0;
   if (it->rho > 0)
     for (int k = 0; k + 1 < N; k++)
-      for (int q = 0; q < NNL; q++) st->viol = fmax(st->viol, it->e[k * NNL + q]);
+      for (int q = 0; q < NNL; q++) st->viol = fmax(st->viol, it->e[k * NNLT + q]);
   it_free(it), it_free(tr);
   free(s->L), free(s->W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu), free(de);
   free(sG1), free(sG2), free(sR);
@@ -1497,6 +1552,21 @@ int oracle_cons_derivs(const ltompc_params* p, const double* tab, int nt, double
     }
   }
   return 0;
+}
+/* friction-ellipse constraints (front, rear): value + gradients + Hessians (2, 2x8, 2x64) */
+int oracle_ell_derivs(const ltompc_params* p, const double* x, double* val, double* grad, double* H) {
+  jet g[NEL];
+  ell_jet(p, x, g);
+  for (int q = 0; q < NEL; q++) {
+    val[q] = g[q].v;
+    for (int a = 0; a < NX; a++) {
+      grad[q * 8 + a] = g[q].g[a];
+      for (int b = 0; b < NX; b++) H[q * 64 + a * 8 + b] = g[q].h[hidx(a, b)];
+    }
+  }
+  double v2[NEL];
+  ell_val(p, x, v2);
+  return (v2[0] == val[0] || fabs(v2[0] - val[0]) <= 1e-12 * fabs(val[0])) ? 0 : -1; /* (the two evaluations agree) */
 }
 int oracle_slip_forces(const ltompc_params* p, const double* x, int batch, double* alpha, double* Fy) {
   for (int b = 0; b < batch; b++) {

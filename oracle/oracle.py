@@ -21,7 +21,8 @@ class Params(C.Structure):
         "mass", "inertia_z", "length_f", "length_r", "width", "B_f", "C_f", "D_f", "B_r", "C_r", "D_r",
         "C_m", "Cr_0", "Cr_2", "gravity", "ptv", "q_n", "q_mu", "q_vy", "q_v", "vref_scale", "q_B")] + [
         ("r_du", C.c_double * 2), ("x_lb", C.c_double * 8), ("x_ub", C.c_double * 8),
-        ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2)]
+        ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2)] + [
+        (n, C.c_double) for n in ("ell_penalty", "ell_rho", "ell_D_f", "ell_D_r")]
 
 
 class Options(C.Structure):
@@ -99,6 +100,13 @@ class Oracle:
         x = np.ascontiguousarray(x, float)
         v, g, H = np.zeros(3), np.zeros((3, 8)), np.zeros((3, 8, 8))
         lib().oracle_cons_derivs(C.byref(self.p), _p(self.tab), self.nt, C.c_double(eps), _p(x), _p(v), _p(g), _p(H))
+        return v, g, H
+
+    def ell_derivs(self, x):
+        x = np.ascontiguousarray(x, float)
+        v, g, H = np.zeros(2), np.zeros((2, 8)), np.zeros((2, 8, 8))
+        rc = lib().oracle_ell_derivs(C.byref(self.p), _p(x), _p(v), _p(g), _p(H))
+        assert rc == 0
         return v, g, H
 
     def slip_forces(self, x):

@@ -116,8 +116,22 @@ def collocation(X, C, U, tab, eps, h=0.1):
     return G1, G2
 
 
-def inequalities(X, C, U, tab, eps):
-    """(N, 23): u bounds, c bounds, x+ bounds, gL/gR+/gR- at x+; h <= 0.  Last row's nl entries are not constraints."""
+def ellipse(x, ell):
+    """Friction-ellipse constraints (model.py:86-99), normalised by the radius: ell = (penalty, rho, D_f, D_r)."""
+    vx, vy, r, de, th = x[..., 3], x[..., 4], x[..., 5], x[..., 6], x[..., 7]
+    af = torch.atan2(vy + P["lf"] * r, vx) - de
+    ar = torch.atan2(vy - P["lr"] * r, vx)
+    L = P["lf"] + P["lr"]
+    Fnf, Fnr = P["lr"] * P["m"] * P["g"] / L, P["lf"] * P["m"] * P["g"] / L
+    Fyf = -Fnf * P["Df"] * torch.sin(P["Cf"] * torch.atan(P["Bf"] * af))
+    Fyr = -Fnr * P["Dr"] * torch.sin(P["Cr"] * torch.atan(P["Br"] * ar))
+    lng = ell[1] * 0.5 * P["Cm"] * th
+    return torch.stack([(lng * lng + Fyf * Fyf) / ell[2] ** 2 - 1.0, (lng * lng + Fyr * Fyr) / ell[3] ** 2 - 1.0], dim=-1)
+
+
+def inequalities(X, C, U, tab, eps, ell=None):
+    """(N, 23 [+ 2]): u bounds, c bounds, x+ bounds, gL/gR+/gR- [, ellipse front / rear] at x+; h <= 0.  Last row's nl entries are
+    not constraints."""
     cols = []
     for idx, sg, val in UB:
         cols.append(sg * (U[:, idx] - val))
@@ -126,13 +140,17 @@ def inequalities(X, C, U, tab, eps):
     for idx, sg, val in XB:
         cols.append(sg * (X[1:, idx] - val))
     g = cons(X[1:], tab, eps)
+    if ell is not None:
+        g = torch.cat([g, ellipse(X[1:], ell)], dim=-1)
     return torch.cat([torch.stack(cols, dim=-1), g], dim=-1)
 
 
-def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 0.1, rho: float = 0.0):
+def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 0.1, rho: float = 0.0, ell=None):
     """Residuals of the KKT conditions of the NLP at solution `sol` (dict with X, C, U, L1, L2, NU of instance b):
     returns dict(stationarity, equality, ineq_violation, complementarity, min_multiplier, objective).
 
+    ell = (penalty, rho_long, D_f, D_r): the two friction-ellipse constraints are present (always soft, penalty ell[0]); returned
+    in addition: ell_violation, ell_complementarity, max_ell_multiplier; the objective includes their penalty.
     rho > 0: the track constraints are softened with an exact L1 penalty, min J + rho sum(e), g - e <= 0, e >= 0.  With
     the elastic variables at their optimum e = max(g, 0) the conditions are: stationarity in (x, c, u) as before,
     0 <= nu <= rho, nu * max(-g, 0) = 0 and (rho - nu) * max(g, 0) = 0; `ineq_violation` then covers the bounds only,
@@ -148,11 +166,21 @@ def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 
     Xall = torch.cat([X[:1], Xf], dim=0)
     J = objective(Xall, U, uprev, tab, eps)
     G1, G2 = collocation(Xall, C, U, tab, eps, h)
-    H = inequalities(Xall, C, U, tab, eps)
+    nnl = 3 if ell is None else 5
+    NU[N - 1, -nnl:] = 0.0
+    H = inequalities(Xall, C, U, tab, eps, ell)
     Lag = J + (L1 * G1).sum() + (L2 * G2).sum() + (NU * H).sum()
     gX, gC, gU = torch.autograd.grad(Lag, [Xf, C, U])
     Hd = H.detach().clone()
-    Hd[N - 1, -3:] = -1.0
+    Hd[N - 1, -nnl:] = -1.0
+    extra = {}
+    if ell is not None:   # split the (always soft) ellipse columns off: the rest is checked as before
+        He, NUe = Hd[:, -2:], NU[:, -2:]
+        Hd, NU = Hd[:, :-2], NU[:, :-2]
+        compe = torch.maximum((NUe * torch.clamp(-He, min=0.0)).abs().max(), ((ell[0] - NUe) * torch.clamp(He, min=0.0)).abs().max())
+        extra = dict(ell_violation=float(torch.clamp(He, min=0.0).max()), ell_complementarity=float(compe), max_ell_multiplier=float(NUe.max()),
+                     min_ell_multiplier=float(NUe.min()))
+        J = J + ell[0] * torch.clamp(He, min=0.0).sum()
     if rho > 0:
         Ht, NUt = Hd[:, -3:], NU[:, -3:]
         comp = torch.maximum((NUt * torch.clamp(-Ht, min=0.0)).abs().max(), ((rho - NUt) * torch.clamp(Ht, min=0.0)).abs().max())
@@ -161,8 +189,8 @@ def kkt_residuals(sol: dict, x0, uprev, tab, eps: float, b: int = 0, h: float = 
                     equality=float(max(G1.detach().abs().max(), G2.detach().abs().max())),
                     ineq_violation=float(Hd[:, :-3].max()), soft_violation=float(torch.clamp(Ht, min=0.0).max()),
                     complementarity=float(comp), min_multiplier=float(NU.min()), max_track_multiplier=float(NUt.max()),
-                    objective=float(J.detach() + rho * torch.clamp(Ht, min=0.0).sum()))
+                    objective=float(J.detach() + rho * torch.clamp(Ht, min=0.0).sum()), **extra)
     return dict(stationarity=float(max(gX.abs().max(), gC.abs().max(), gU.abs().max())),
                 equality=float(max(G1.detach().abs().max(), G2.detach().abs().max())),
                 ineq_violation=float(Hd.max()), complementarity=float((NU * Hd).abs().max()),
-                min_multiplier=float(NU.min()), objective=float(J.detach()))
+                min_multiplier=float(NU.min()), objective=float(J.detach()), **extra)
