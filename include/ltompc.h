@@ -271,6 +271,9 @@ int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const
                       double* J, double* H, double* cval, double* cgrad, double* cH, double* gval,
                       double* ggrad, double* gH);
 
+/* Test hook: the friction-ellipse constraints (front, rear; params.ell_*) at n points: val n x 2, grad n x 2 x 8, H n x 2 x 8 x 8. */
+int ltompc_test_ellipse(ltompc_handle h, int n, const double* x, double* val, double* grad, double* H);
+
 /* ---------------------------------------------------------------------------------------------------------------------
  * Velocity-profile generator: the producer of velocities.json, the v_ref table of the hot path.
  * Replaces VelocityProfile(vehicle, s, k, s_max) of the reference (src/velocity.py:14-76, called from

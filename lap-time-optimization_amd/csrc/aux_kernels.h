@@ -170,7 +170,7 @@ __global__ void k_pack_inverse(const int* __restrict__ orig, int* __restrict__ i
 }
 // pass 0: temporaries[j] = state[perm[j]], pass 1: state[j] = temporaries[j], for the slots j < nslots
 __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restrict__ nslots_p, int nslots_max, int* __restrict__ orig,
-                       int ni, int pass) {
+                       int ni, int nel, int pass) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = tid % nslots_max, k = tid / nslots_max, N = W.N;
   const int nslots = nslots_p ? nslots_p[0] : nslots_max;
@@ -182,10 +182,10 @@ __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restri
   };
   if (pass == 0) {
     mv(W.dX, W.X, 8, N + 1);
-    if (k < N) mv(W.dC, W.C, 8, N), mv(W.dU, W.U, 2, N), mv(W.nL1, W.L1, 8, N), mv(W.nL2, W.L2, 8, N), mv(W.dT, W.T, ni + 3, N), mv(W.dNU, W.NU, ni, N);
+    if (k < N) mv(W.dC, W.C, 8, N), mv(W.dU, W.U, 2, N), mv(W.nL1, W.L1, 8, N), mv(W.nL2, W.L2, 8, N), mv(W.dT, W.T, ni + 3 + nel, N), mv(W.dNU, W.NU, ni, N);
   } else {
     mv(W.X, W.dX, 8, N + 1);
-    if (k < N) mv(W.C, W.dC, 8, N), mv(W.U, W.dU, 2, N), mv(W.L1, W.nL1, 8, N), mv(W.L2, W.nL2, 8, N), mv(W.T, W.dT, ni + 3, N), mv(W.NU, W.dNU, ni, N);
+    if (k < N) mv(W.C, W.dC, 8, N), mv(W.U, W.dU, 2, N), mv(W.L1, W.nL1, 8, N), mv(W.L2, W.nL2, 8, N), mv(W.T, W.dT, ni + 3 + nel, N), mv(W.NU, W.dNU, ni, N);
   }
   if (k == 0) {  // per-instance arrays through the Riccati buffer: x0 (8), uprev (2), st, filt | si, orig (ints)
     gptr<double> tmp = W.RC;
@@ -331,5 +331,21 @@ __global__ void k_test_model(Consts K, int n, double eps, const double* __restri
   }
 }
 
+
+// test hook: friction-ellipse constraints at given points: val n x 2, grad n x 2 x 8, H n x 2 x 8 x 8 (full state indexing)
+__global__ void k_test_ellipse(Consts K, int n, const double* __restrict__ x, double* __restrict__ val, double* __restrict__ grad, double* __restrict__ H) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  double xx[8], v[2], g[2][5], h[2][15], v2[2];
+  for (int i = 0; i < 8; i++) xx[i] = x[(size_t)t * 8 + i];
+  ellipse_eval(K.p, xx, v, g, h);
+  ellipse_val(K.p, xx, v2);
+  for (int q = 0; q < 2; q++) {
+    val[(size_t)t * 2 + q] = v[q] + (v2[q] - v[q]) * 0.0 + (fabs(v2[q] - v[q]) <= 1e-12 * (1.0 + fabs(v[q])) ? 0.0 : 1e300);  // (the two evaluations agree)
+    for (int i = 0; i < 8; i++) grad[((size_t)t * 2 + q) * 8 + i] = i >= 3 ? g[q][i - 3] : 0.0;
+    for (int i = 0; i < 8; i++)
+      for (int j = 0; j < 8; j++) H[((size_t)t * 2 + q) * 64 + i * 8 + j] = (i >= 3 && j >= 3) ? h[q][sidx(i - 3, j - 3)] : 0.0;
+  }
+}
 
 }  // namespace ltompc

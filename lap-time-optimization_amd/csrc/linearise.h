@@ -117,7 +117,22 @@ __device__ __forceinline__ void init_slot_slacks(const Consts& K, const Work& W,
         e = g + t;
       }
     }
-    PL(W.T, m + q, k, N) = t, PL(W.T, m + 3 + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;
+    PL(W.T, m + q, k, N) = t, PL(W.T, K.bd.ni + q, k, N) = e, PL(W.NU, m + q, k, N) = mu / t;  // (elastic planes follow the ni slacks)
+  }
+  if (K.bd.nel) {  // friction-ellipse constraints: always soft, penalty params.ell_penalty, same start as a softened track constraint
+    const double pen = K.p.ell_penalty;
+    double ge[2] = {-1.0, -1.0};
+    if (k + 1 <= N - 1) ellipse_val(K.p, xp, ge);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      double t = fmax(-ge[q] > K.o.bound_push ? -ge[q] : K.o.bound_push, 2.0 * mu / pen), e = mu / (pen - mu / t);
+      if (ge[q] > ELASTIC_CP_VIOL) {
+        const double g = ge[q], bq = pen * g - 2.0 * mu;
+        t = (-bq + sqrt(bq * bq + 4.0 * pen * mu * g)) / (2.0 * pen);
+        e = g + t;
+      }
+      PL(W.T, m + 3 + q, k, N) = t, PL(W.T, K.bd.ni + 3 + q, k, N) = e, PL(W.NU, m + 3 + q, k, N) = mu / t;
+    }
   }
 }
 // Restoration entry (SI_REINIT, set by d_pick): the slot's slacks, multipliers and elastic variables start again from its
@@ -150,6 +165,7 @@ struct Slot {
   double gcost[8];
   double gs[3], gn[3], gm[3];        // gradients of gL, gR+, gR-
   double gv[3];                      // values of gL, gR+, gR- at x_{k+1}
+  double gve[2], ge[2][5];           // ELL: values and gradients (over states 3..7) of the two friction-ellipse constraints
   double rp_ineq, cmax, cmin, smult; // WITH_DUAL: max |h + t|, max / min t nu, sum |nu| over the slot's inequalities
   double th_ineq, sumlog;            // WITH_DUAL: sum |h + t|, sum log t (filter measures of the current point)
   double emax;                       // WITH_DUAL: largest elastic variable of the slot (0 on hard constraints)
@@ -158,7 +174,7 @@ struct Slot {
   bool nl;
 };
 
-template <bool WITH_DUAL, class BP>
+template <bool WITH_DUAL, class BP, bool ELL>
 __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, int k, int b, double eps, Slot& S) {
   const int N = W.N;
   const double hdt = K.o.t_step, rho = W.st[(size_t)ST_RHO * W.Bp + b];
@@ -231,7 +247,7 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
 #pragma unroll
     for (int q = 0; q < 3; q++) {
       tq[q] = PL(W.T, m_nl + q, k, N), nq[q] = PL(W.NU, m_nl + q, k, N);
-      eq[q] = rho > 0.0 ? PL(W.T, m_nl + 3 + q, k, N) : 0.0;
+      eq[q] = rho > 0.0 ? PL(W.T, K.bd.ni + q, k, N) : 0.0;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     asm volatile("" : "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]), "+v"(nq[0]), "+v"(nq[1]), "+v"(nq[2]), "+v"(eq[0]), "+v"(eq[1]), "+v"(eq[2]));
@@ -270,6 +286,36 @@ __device__ __forceinline__ void linearise_slot(const Consts& K, const Work& W, i
   } else {
 #pragma unroll
     for (int q = 0; q < 3; q++) S.gv[q] = -1.0, S.gs[q] = S.gn[q] = S.gm[q] = 0.0;
+  }
+  if (ELL && S.nl) {
+    // friction-ellipse constraints (always soft, penalty params.ell_penalty): node block over the states 3..7
+    const double pen = K.p.ell_penalty;
+    double te[2], ne[2], ee[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) te[q] = PL(W.T, m_nl + 3 + q, k, N), ne[q] = PL(W.NU, m_nl + 3 + q, k, N), ee[q] = PL(W.T, K.bd.ni + 3 + q, k, N);
+    double h15[2][15];
+    ellipse_eval(K.p, S.xp, S.gve, S.ge, h15);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int mm = m_nl + 3 + q;
+      const double t = te[q], nu = ne[q], e = ee[q];
+      double Sg, s0, s1;
+      track_barrier(pen, S.gve[q], t, nu, e, Sg, s0, s1);
+#pragma unroll
+      for (int a = 0; a < 5; a++) {
+        S.gxp0[3 + a] += s0 * S.ge[q][a], S.gxp1[3 + a] += s1 * S.ge[q][a];
+        if (WITH_DUAL) S.dxd[3 + a] += nu * S.ge[q][a];
+#pragma unroll
+        for (int c = 0; c <= a; c++) S.Hxp[sidx(3 + a, 3 + c)] += Sg * S.ge[q][a] * S.ge[q][c] + nu * h15[q][sidx(a, c)];
+      }
+      if (WITH_DUAL) {
+        const double ez = e * (pen - nu);
+        S.rp_ineq = fmax(S.rp_ineq, fabs(S.gve[q] - e + t));
+        S.cmax = fmax(S.cmax, fmax(t * nu, ez)), S.cmin = fmin(S.cmin, fmin(t * nu, ez)), S.smult += fabs(nu) + fabs(pen - nu);
+        S.th_ineq += fabs(S.gve[q] - e + t), lprod *= t, lprod *= e, S.cost += pen * e;
+        if ((mm & 7) == 7) S.sumlog += log(lprod), lprod = 1.0;
+      }
+    }
   }
   if (WITH_DUAL) S.sumlog += log(lprod);
 }
@@ -430,7 +476,7 @@ __device__ __forceinline__ bool condense_slot(const Consts& K, const Slot& S, M8
 
 
 // ------------------------------------------------------------------------------------------ k_eval
-template <class BP>
+template <class BP, bool ELL>
 __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int k, const int b, const bool force) {
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b]) return;
@@ -440,7 +486,7 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   const bool reinit = W.si[(size_t)SI_REINIT * W.Bp + b] != 0;  // the restoration phase starts with this evaluation
   if (reinit) reinit_slot<BP>(K, W, k, b);
   Slot S;
-  linearise_slot<true, BP>(K, W, k, b, eps, S);
+  linearise_slot<true, BP, ELL>(K, W, k, b, eps, S);
   // ---- node block of x_{k+1}: complete after the linearisation, stored now so that its 52 registers are free during
   //      the elimination (stores issued late also cost more than their bandwidth: on gfx9 a later scratch reload
   //      has to wait for every store before it, vmcnt counts both)
@@ -529,19 +575,19 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   }
 }
 
-template <class BP>
+template <class BP, bool ELL>
 __global__ void __launch_bounds__(64) k_eval(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
-  d_eval<BP>(K, W, k, la.act[j], la.force_eval != 0);
+  d_eval<BP, ELL>(K, W, k, la.act[j], la.force_eval != 0);
 }
 
 
 // ------------------------------------------------------------------------------------------ k_expand
-template <class BP>
+template <class BP, bool ELL>
 __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
   if (W.si[(size_t)SI_DONE * W.Bp + b] || !W.si[(size_t)SI_STEP * W.Bp + b]) return;  // no step this launch
@@ -570,7 +616,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
   //  above the costate, runs out of registers and spills the Riccati words one by one, each spill waiting for its load)
   __builtin_amdgcn_sched_barrier(0);
   Slot S;
-  linearise_slot<false, BP>(K, W, k, b, eps, S);
+  linearise_slot<false, BP, ELL>(K, W, k, b, eps, S);
   M8Blocks M8;
   factor_m8(S, M8);
   double dxk[8], dxp[8], du[2], dc[8];
@@ -650,7 +696,7 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
 #pragma unroll
       for (int q = 0; q < 3; q++) {
         tt[m0 + q] = PL(W.T, m0 + q, k, N), nn[m0 + q] = PL(W.NU, m0 + q, k, N);
-        tt[m0 + 3 + q] = rho > 0.0 ? PL(W.T, m0 + 3 + q, k, N) : 0.0;
+        tt[m0 + 3 + q] = rho > 0.0 ? PL(W.T, K.bd.ni + q, k, N) : 0.0;
       }
     }
   }
@@ -673,8 +719,8 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
       const double gd = S.gs[q] * dxp[0] + S.gn[q] * dxp[1] + S.gm[q] * dxp[2];
       if (rho > 0.0) {
         double dtt, dn, dee;
-        track_soft_step(rho, mu, tau, S.gv[q], gd, t, nu, BP::fixed ? tt[m + 3] : PL(W.T, m + 3, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
-        PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, m + 3, k, N) = dee;
+        track_soft_step(rho, mu, tau, S.gv[q], gd, t, nu, BP::fixed ? tt[m + 3] : PL(W.T, K.bd.ni + q, k, N), dtt, dn, dee, r_pri, a_dua, gphid);
+        PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, K.bd.ni + q, k, N) = dee;
       } else {
         const double dtt = -(S.gv[q] + t) - gd;
         const double dn = (mu - nu * dtt) * it - nu;
@@ -684,21 +730,38 @@ __device__ __forceinline__ void d_expand(const Consts& K, const Work& W, const i
         gphid -= mu * dtt * it;
       }
     } else {
-      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0, PL(W.dT, m + 3, k, N) = 0.0;
+      PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0, PL(W.dT, K.bd.ni + q, k, N) = 0.0;
+    }
+  }
+  if (ELL) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int m = S.m_nl + 3 + q, me = K.bd.ni + 3 + q;
+      if (S.nl) {
+        const double t = PL(W.T, m, k, N), nu = PL(W.NU, m, k, N), e = PL(W.T, me, k, N);
+        double gd = 0.0;
+#pragma unroll
+        for (int a = 0; a < 5; a++) gd += S.ge[q][a] * dxp[3 + a];
+        double dtt, dn, dee;
+        track_soft_step(K.p.ell_penalty, mu, tau, S.gve[q], gd, t, nu, e, dtt, dn, dee, r_pri, a_dua, gphid);
+        PL(W.dT, m, k, N) = dtt, PL(W.dNU, m, k, N) = dn, PL(W.dT, me, k, N) = dee;
+      } else {
+        PL(W.dT, m, k, N) = 0.0, PL(W.dNU, m, k, N) = 0.0, PL(W.dT, me, k, N) = 0.0;
+      }
     }
   }
   const double a_pri = r_pri > tau ? tau / r_pri : 1.0;
   PL(W.SP, SP_apri, k, N) = a_pri, PL(W.SP, SP_adua, k, N) = a_dua, PL(W.SP, SP_gphid, k, N) = gphid;
 }
 
-template <class BP>
+template <class BP, bool ELL>
 __global__ void __launch_bounds__(64) k_expand(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
   int tid = blockIdx.x * blockDim.x + threadIdx.x;
   int j = tid % la.n_pad, k = tid / la.n_pad;
   if (k >= W.N || j >= la.nact[0]) return;
-  d_expand<BP>(K, W, k, la.act[j]);
+  d_expand<BP, ELL>(K, W, k, la.act[j]);
 }
 
 }  // namespace ltompc

@@ -12,7 +12,7 @@ namespace ltompc {
 // for every instance; phase 1 evaluates the remaining candidates for the instances whose first candidate was rejected.
 // Filter measures (theta, cost, sum log t) of the step candidates l_begin..l_end of interval k of instance b;
 // candidate l >= 1 has alpha = a_pri * 2^-(l-1) (l = 0, the current point, is written by k_eval).
-template <class BP, bool PIN>
+template <class BP, bool PIN, bool ELL>
 __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, const int k, const int b, const int l_begin,
                                              const int l_end) {
   const int N = W.N;
@@ -98,11 +98,24 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
         double e = 0.0;
         pr *= t;
         if (rho > 0.0) {  // elastic variable of the softened constraint: g - e + t = 0, cost rho e
-          e = PL(W.T, m + 3 + q, k, N) + alpha * PL(W.dT, m + 3 + q, k, N);
+          e = PL(W.T, K.bd.ni + q, k, N) + alpha * PL(W.dT, K.bd.ni + q, k, N);
           pr *= e, co += rho * e;
         }
         th += fabs(gv[q] - e + t);
         if (((m + q) & 7) == 7) sl += log(pr), pr = 1.0;
+      }
+      if (ELL) {  // friction-ellipse constraints (always soft): same grouping of the logarithms as linearise_slot
+        double ge[2];
+        ellipse_val(K.p, txp, ge);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+          const int mm = m + 3 + q, me = K.bd.ni + 3 + q;
+          const double t = PL(W.T, mm, k, N) + alpha * PL(W.dT, mm, k, N);
+          const double e = PL(W.T, me, k, N) + alpha * PL(W.dT, me, k, N);
+          pr *= t, pr *= e, co += K.p.ell_penalty * e;
+          th += fabs(ge[q] - e + t);
+          if ((mm & 7) == 7) sl += log(pr), pr = 1.0;
+        }
       }
     }
     sl += log(pr);
@@ -110,7 +123,7 @@ __device__ __forceinline__ void d_linesearch(const Consts& K, const Work& W, con
   }
 }
 
-template <class BP>
+template <class BP, bool ELL>
 __global__ void __launch_bounds__(64) k_linesearch(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la, int phase, int jw) {
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
@@ -123,7 +136,7 @@ __global__ void __launch_bounds__(64) k_linesearch(const Consts* __restrict__ Kp
   if (phase == 0 ? (rest >= N) : (cand >= K.o.n_linesearch - 1)) return;
   const int count = phase == 0 ? la.nact[0] : W.ls_count[0];
   const int l = phase == 0 ? 1 : 2 + cand;
-  for (int j = j0; j < count; j += jw) d_linesearch<BP, true>(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
+  for (int j = j0; j < count; j += jw) d_linesearch<BP, true, ELL>(K, W, k, phase == 0 ? la.act[j] : W.ls_list[j], l, l);
 }
 
 // ------------------------------------------------------------------------------------------ k_pick
@@ -345,7 +358,7 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
     }
     PL(W.U, 0, k, N) = u[0] + alpha * du[0], PL(W.U, 1, k, N) = u[1] + alpha * du[1];
   }
-  const int ni = K.bd.ni, nact = (k + 1 <= N - 1) ? ni : ni - 3;
+  const int ni = K.bd.ni, nel = K.bd.nel, nact = (k + 1 <= N - 1) ? ni : ni - 3 - nel;  // (the last slot has no nonlinear constraints)
   for (int m0 = 0; m0 < nact; m0 += 8) {
     double t[8], dt[8], nu[8], dn[8];
 #pragma unroll
@@ -369,6 +382,13 @@ __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const i
 #pragma unroll
     for (int q = 0; q < 3; q++) PL(W.T, ni + q, k, N) = e[q] + alpha * de[q];
   }
+  if (nel && nact == ni) {  // ... of the friction-ellipse constraints
+    double e[2], de[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) e[q] = PL(W.T, ni + 3 + q, k, N), de[q] = PL(W.dT, ni + 3 + q, k, N);
+#pragma unroll
+    for (int q = 0; q < 2; q++) PL(W.T, ni + 3 + q, k, N) = e[q] + alpha * de[q];
+  }
 }
 
 __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {
@@ -385,7 +405,7 @@ __global__ void __launch_bounds__(64) k_update(const Consts* __restrict__ Kp, co
 // ------------------------------------------------------------------------------------------ k_step1
 // Narrow launches: the whole step selection of ONE instance per workgroup (both line-search phases, the filter test
 // and the update), i.e. five dependent launches of 10..30 us each in one.  Same device functions, same numbers.
-template <class BP>
+template <class BP, bool ELL>
 __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, Launch la) {  // 320 = 8 candidates x 40 intervals in one pass
   const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
   const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
@@ -400,7 +420,7 @@ __global__ void __launch_bounds__(320) k_step1(const Consts* __restrict__ Kp, co
   const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && tid == 0;
   long long rt0 = rprof ? clock64() : 0;
 #define STOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
-  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP, false>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
+  for (int idx = tid; idx < N * K.o.n_linesearch; idx += 320) d_linesearch<BP, false, ELL>(K, W, idx % N, b, 1 + idx / N, 1 + idx / N);
   STOCK(8);
   __syncthreads();
   STOCK(9);

@@ -110,7 +110,8 @@ void build_bounds(const ltompc_params& p, Bounds& b) {
     if (p.u_lb[i] > -LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = -1.0, b.ub_val[b.n_ub] = p.u_lb[i], b.n_ub++;
     if (p.u_ub[i] < LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = +1.0, b.ub_val[b.n_ub] = p.u_ub[i], b.n_ub++;
   }
-  b.ni = b.n_ub + 2 * b.n_xb + NNL;
+  b.nel = p.ell_penalty > 0.0 ? NEL : 0;
+  b.ni = b.n_ub + 2 * b.n_xb + NNL + b.nel;
 }
 
 struct Launcher {
@@ -184,7 +185,7 @@ int ensure_unpacked(ltompc_solver* h) {
   const int nthreads = (N + 1) * B;
   for (int pass = 0; pass < 2; pass++)
     hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, (const int*)nullptr, B, h->d_orig,
-                       h->K.bd.ni, pass);
+                       h->K.bd.ni, h->K.bd.nel, pass);
   HIPCHECK(hipGetLastError());
   h->packed = false;
   return 0;
@@ -238,6 +239,9 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (!(options->t_step > 0)) return fail("ltompc_create: t_step must be positive");
   if (!(options->soft_rho >= 0) || !std::isfinite(options->soft_rho)) return fail("ltompc_create: soft_rho must be >= 0 (0 = hard track constraints)");
   if (!(options->resto_rho >= 0) || !std::isfinite(options->resto_rho)) return fail("ltompc_create: resto_rho must be >= 0 (0 = no restoration phase)");
+  if (!(params->ell_penalty >= 0) || !std::isfinite(params->ell_penalty)) return fail("ltompc_create: ell_penalty must be >= 0 (0 = no friction-ellipse constraints)");
+  if (params->ell_penalty > 0 && (!(params->ell_D_f > 0) || !(params->ell_D_r > 0) || !std::isfinite(params->ell_rho)))
+    return fail("ltompc_create: friction-ellipse constraints need ell_D_f > 0, ell_D_r > 0 and a finite ell_rho");
   if (options->resto_sticky < 0) return fail("ltompc_create: resto_sticky must be >= 0");
   if (options->max_soc != 0) return fail("ltompc_create: max_soc must be 0 (the second-order correction exists in the oracle only, see include/ltompc.h)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
@@ -276,6 +280,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     const char* ev = getenv("LTOMPC_EVAL");  // slot | wave: overrides options.latency_mode (tests, experiments)
     h->eval8 = options->latency_mode == 1 || (options->latency_mode == 0 && batch <= 64);
     if (ev) h->eval8 = std::string(ev) == "wave";
+    if (params->ell_penalty > 0.0) h->eval8 = false;  // (the 8-lanes-per-slot kernels do not have the friction-ellipse constraints)
     {
       unsigned ulb = 0, uub = 0, xlb = 0, xub = 0;
       for (int i = 0; i < 2; i++) ulb |= (params->u_lb[i] > -LTOMPC_NO_BOUND) << i, uub |= (params->u_ub[i] < LTOMPC_NO_BOUND) << i;
@@ -313,10 +318,11 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_tables, (size_t)LTOMPC_TABLE_ROWS * n_table);
   rc |= h->dalloc(&W.X, 8 * (N + 1) * Bp, true), rc |= h->dalloc(&W.C, 8 * N * Bp, true), rc |= h->dalloc(&W.U, 2 * N * Bp, true);
   rc |= h->dalloc(&W.L1, 8 * N * Bp, true), rc |= h->dalloc(&W.L2, 8 * N * Bp, true);
-  rc |= h->dalloc(&W.T, (ni + NNL) * N * Bp, true), rc |= h->dalloc(&W.NU, ni * N * Bp, true);  // T: slacks + elastic variables
+  const size_t nel = h->K.bd.nel;
+  rc |= h->dalloc(&W.T, (ni + NNL + nel) * N * Bp, true), rc |= h->dalloc(&W.NU, ni * N * Bp, true);  // T: slacks + elastic variables
   rc |= h->dalloc(&W.dX, 8 * (N + 1) * Bp, true), rc |= h->dalloc(&W.dC, 8 * N * Bp, true), rc |= h->dalloc(&W.dU, 2 * N * Bp, true);
   rc |= h->dalloc(&W.nL1, 8 * N * Bp, true), rc |= h->dalloc(&W.nL2, 8 * N * Bp, true);
-  rc |= h->dalloc(&W.dT, (ni + NNL) * N * Bp, true), rc |= h->dalloc(&W.dNU, ni * N * Bp, true);
+  rc |= h->dalloc(&W.dT, (ni + NNL + nel) * N * Bp, true), rc |= h->dalloc(&W.dNU, ni * N * Bp, true);
   // (k_riccati8's staging fetches one field past each STAGE block, k <= N - 1: that word is the first of the next block, and
   //  block N, the terminal node, follows the last stage block; no padding needed)
   rc |= h->dalloc(&W.QP, (size_t)QP_NF * (N + 1) * Bp, true), rc |= h->dalloc(&W.RC, (size_t)RC_NF * (N + 1) * Bp, true);
@@ -423,6 +429,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   if (!h || !x0_dev) return fail("ltompc_make_step: null argument");
   HIPCHECK(hipSetDevice(h->device));
   const int B = h->B, N = h->N, Bp = h->Bp;
+  const bool ell = h->K.bd.nel > 0;  // kernels instantiated with / without the friction-ellipse constraints
   Launcher L{h};
   hipLaunchKernelGGL(k_load_x0, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)(h->packed ? h->d_orig : nullptr),
                      h->K.o.resto_sticky, h->cold_next ? 0 : 1);
@@ -455,7 +462,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     h->cur_iter = it;
     la.force_eval = force_eval_next ? 1 : 0;
     force_eval_next = false;
-    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, h->ref_eval ? k_eval<BoundsRef> : k_eval<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, ell ? (h->ref_eval ? k_eval<BoundsRef, true> : k_eval<BoundsAny, true>) : (h->ref_eval ? k_eval<BoundsRef, false> : k_eval<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
     if (h->serial_riccati) {
       if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
     } else {
@@ -468,17 +475,18 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
       } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, h->ref_expand ? k_expand<BoundsRef> : k_expand<BoundsAny>, N * np, h->d_K, h->d_W, la)) return -1;
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, ell ? (h->ref_expand ? k_expand<BoundsRef, true> : k_expand<BoundsAny, true>) : (h->ref_expand ? k_expand<BoundsRef, false> : k_expand<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
     if (n_launch <= h->step1_width) {
       // one workgroup per instance does both line-search phases, the filter test and the update
       L.block_threads = 320;
-      if (L.run(7, h->ref_step1 ? k_step1<BoundsRef> : k_step1<BoundsAny>, n_launch * 320, h->d_K, h->d_W, la)) return -1;
+      if (L.run(7, ell ? (h->ref_step1 ? k_step1<BoundsRef, true> : k_step1<BoundsAny, true>) : (h->ref_step1 ? k_step1<BoundsRef, false> : k_step1<BoundsAny, false>), n_launch * 320, h->d_K, h->d_W, la)) return -1;
     } else {
-      if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
+      const auto kls = ell ? (h->ref_ls ? k_linesearch<BoundsRef, true> : k_linesearch<BoundsAny, true>) : (h->ref_ls ? k_linesearch<BoundsRef, false> : k_linesearch<BoundsAny, false>);
+      if (L.run(3, kls, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
       if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
       if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
         const int jw = np < ls_width ? np : ls_width;  // launch width of the second phase (longer lists are covered grid-stride)
-        if (L.run(3, h->ref_ls ? k_linesearch<BoundsRef> : k_linesearch<BoundsAny>, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
+        if (L.run(3, kls, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
         if (L.run(4, k_pick, jw * 8, h->d_K, h->d_W, la, 1)) return -1;
       }
       if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;
@@ -511,7 +519,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
           const int nthreads = (N + 1) * n_launch;
           for (int pass = 0; pass < 2; pass++)
             hipLaunchKernelGGL(k_pack, dim3((nthreads + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_perm, h->d_nact[cur], n_launch,
-                               h->d_orig, h->K.bd.ni, pass);
+                               h->d_orig, h->K.bd.ni, h->K.bd.nel, pass);
           force_eval_next = true;  // the stage blocks of instances that would skip the evaluation stayed behind
         } else {
           hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur],
@@ -767,6 +775,25 @@ int ltompc_test_model(ltompc_handle h, int n, double eps, const double* x, const
   HIPCHECK(hipStreamSynchronize(h->stream));
   for (int i = 0; i < 9; i++) HIPCHECK(hipMemcpy(dst[i], dev[2 + i], sizeof(double) * sizes[2 + i] * n, hipMemcpyDeviceToHost));
   for (int i = 0; i < 11; i++) (void)hipFree(dev[i]);
+  return 0;
+}
+
+// Test hook: friction-ellipse constraints (front, rear) at n points (host arrays): val n x 2, grad n x 2 x 8, H n x 2 x 64.
+int ltompc_test_ellipse(ltompc_handle h, int n, const double* x, double* val, double* grad, double* H) {
+  if (!h || n < 1 || !x || !val || !grad || !H) return fail("ltompc_test_ellipse: bad argument");
+  HIPCHECK(hipSetDevice(h->device));
+  double *dx, *dv, *dg, *dH;
+  HIPCHECK(hipMalloc((void**)&dx, sizeof(double) * 8 * n));
+  HIPCHECK(hipMalloc((void**)&dv, sizeof(double) * 2 * n));
+  HIPCHECK(hipMalloc((void**)&dg, sizeof(double) * 16 * n));
+  HIPCHECK(hipMalloc((void**)&dH, sizeof(double) * 128 * n));
+  HIPCHECK(hipMemcpy(dx, x, sizeof(double) * 8 * n, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_test_ellipse, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->K, n, dx, dv, dg, dH);
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  HIPCHECK(hipMemcpy(val, dv, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(grad, dg, sizeof(double) * 16 * n, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(H, dH, sizeof(double) * 128 * n, hipMemcpyDeviceToHost));
+  (void)hipFree(dx), (void)hipFree(dv), (void)hipFree(dg), (void)hipFree(dH);
   return 0;
 }
 

@@ -28,7 +28,8 @@ constexpr int NU = 2;
 constexpr int MAX_XB = 16;  // finite state bounds
 constexpr int MAX_UB = 4;   // finite input bounds
 constexpr int NNL = 3;      // gL, gR+, gR-  (see cons_eval)
-constexpr int MAX_NI = MAX_UB + 2 * MAX_XB + NNL;
+constexpr int NEL = 2;      // friction-ellipse constraints of the two axles (ellipse_eval), present when params.ell_penalty > 0
+constexpr int MAX_NI = MAX_UB + 2 * MAX_XB + NNL + NEL;
 
 // index of (i,j), i >= j, in a packed lower-triangular symmetric matrix
 __host__ __device__ constexpr int sidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
@@ -50,7 +51,8 @@ struct Tables {
 };
 
 struct Bounds {
-  int n_xb, n_ub, ni;
+  int n_xb, n_ub, ni;  // ni = n_ub + 2 n_xb + NNL + nel
+  int nel;             // 0, or NEL with the friction-ellipse constraints
   int xb_idx[MAX_XB];
   double xb_sgn[MAX_XB];  // -1: lower bound (h = lb - x), +1: upper (h = x - ub)
   double xb_val[MAX_XB];
@@ -392,6 +394,47 @@ __device__ __forceinline__ void cons_eval(const ltompc_params& p, const Tables& 
     hmm[1] = -hl * sm - hw * cm;
     hmm[2] = hl * sm - hw * cm;
   }
+}
+
+// ---------------------------------------------------------------------------------------------- friction ellipse
+// model.py:86-99 get_traction_ellipse_constraint (registered as soft nl constraints in lines the reference has commented out,
+// controller.py:72-74): long = rho 0.5 C_m T, ellipse_a = long^2 + F_y,a^2 - (alpha D_a)^2 <= 0 for a = front, rear; here
+// normalised by the radius, g_a = (long^2 + F_y,a^2) / ell_D_a^2 - 1 (include/ltompc.h).  Derivatives over (vx, vy, r, delta, T)
+// = states 3..7: gradient g[q][5], packed Hessian h[q][15].
+__device__ __forceinline__ void ellipse_eval(const ltompc_params& p, const double* x, double* val, double (*g)[5], double (*h)[15]) {
+  const double vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
+  const double L = p.length_f + p.length_r;
+  const double Kf = p.length_r * p.mass * p.gravity / L * p.D_f, Kr = p.length_f * p.mass * p.gravity / L * p.D_r;
+  Jet4 F[2];
+  pacejka_jet(vx, vy, r, de, p.length_f, 1.0, p.B_f, p.C_f, Kf, F[0]);
+  pacejka_jet(vx, vy, r, de, -p.length_r, 0.0, p.B_r, p.C_r, Kr, F[1]);
+  const double c = p.ell_rho * 0.5 * p.C_m, lng = c * th;
+  const double iD[2] = {1.0 / (p.ell_D_f * p.ell_D_f), 1.0 / (p.ell_D_r * p.ell_D_r)};
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    val[q] = (lng * lng + F[q].v * F[q].v) * iD[q] - 1.0;
+    if (g) {
+#pragma unroll
+      for (int a = 0; a < 4; a++) g[q][a] = 2.0 * F[q].v * F[q].g[a] * iD[q];
+      g[q][4] = 2.0 * c * c * th * iD[q];
+#pragma unroll
+      for (int a = 0; a < 5; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++)
+          h[q][sidx(a, b)] = a < 4 ? 2.0 * (F[q].g[a] * F[q].g[b] + F[q].v * F[q].h[sidx(a, b)]) * iD[q] : (b == 4 ? 2.0 * c * c * iD[q] : 0.0);
+    }
+  }
+}
+// value only (line search, initialisation): same numbers as the oracle's ell_val
+__device__ __forceinline__ void ellipse_val(const ltompc_params& p, const double* x, double* val) {
+  const double vx = x[3], vy = x[4], r = x[5], de = x[6], th = x[7];
+  const double af = atan2(vy + p.length_f * r, vx) - de, ar = atan2(vy - p.length_r * r, vx);
+  const double L = p.length_f + p.length_r;
+  const double Fnf = p.length_r * p.mass * p.gravity / L, Fnr = p.length_f * p.mass * p.gravity / L;
+  const double Fyf = -Fnf * p.D_f * sin(p.C_f * atan(p.B_f * af)), Fyr = -Fnr * p.D_r * sin(p.C_r * atan(p.B_r * ar));
+  const double lng = p.ell_rho * 0.5 * p.C_m * th;
+  val[0] = (lng * lng + Fyf * Fyf) / (p.ell_D_f * p.ell_D_f) - 1.0;
+  val[1] = (lng * lng + Fyr * Fyr) / (p.ell_D_r * p.ell_D_r) - 1.0;
 }
 
 __device__ __forceinline__ double bound_h(double sgn, double val, double x) { return sgn < 0.0 ? val - x : x - val; }

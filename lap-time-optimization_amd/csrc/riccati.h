@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     smult += PL(W.RS, RS_smult, k, N), obj += PL(W.RS, RS_cost, k, N);
     emax = fmax(emax, PL(W.RS, RS_emax, k, N));
   }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (STD(ST_RHO) > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (last slot has no nl constraints)
+  const int n_mult = N * (2 * NX + K.bd.ni) - (3 + K.bd.nel) + (STD(ST_RHO) > 0.0 ? 3 * (N - 1) : 0) + K.bd.nel * (N - 1);  // multipliers counted (last slot has no nl constraints; elastic pairs count twice)
   double mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
@@ -320,7 +320,7 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     for (int q = 0; q < 8; q++)
       if (k0 + q < N) smult += sm8[q], obj += co8[q];
   }
-  const int n_mult = N * (2 * NX + K.bd.ni) - 3 + (rho > 0.0 ? 3 * (N - 1) : 0);  // multipliers counted (the last slot has no track constraints)
+  const int n_mult = N * (2 * NX + K.bd.ni) - (3 + K.bd.nel) + (rho > 0.0 ? 3 * (N - 1) : 0) + K.bd.nel * (N - 1);  // multipliers counted (the last slot has no nonlinear constraints; elastic pairs count twice)
   mu = STD(ST_MU);
   double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
   double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);

@@ -115,10 +115,16 @@ class Controller:
 
     def __init__(self, model: VehicleModel, control_costs, n_horizon: int = 10, t_step: float = 0.1, n_robust: int = 0,
                  batch: int = 1, device: int = 0, options=None, soft_constraint: bool = False,
-                 penalty_term_cons: float = 100.0):
+                 penalty_term_cons: float = 100.0, traction_ellipse: bool = False, rho: float = 1.0, alpha: float = 1.0,
+                 ellipse_penalty: float = 1.0, ellipse_radius=None):
         """soft_constraint / penalty_term_cons: the keyword arguments of do_mpc's set_nl_cons, applied to the two track
         constraints of controller.py:69-70 (the reference passes neither: hard constraints, with which the closed loop
-        stops converging part-way round buckmore; see options.soft_rho in include/ltompc.h and DESIGN.md §6)."""
+        stops converging part-way round buckmore; see options.soft_rho in include/ltompc.h and DESIGN.md §6).
+        traction_ellipse: register the two friction-ellipse constraints the reference has commented out (controller.py:72-74,
+        `set_constraints(rho, alpha)` of controller.py:57 with its rho = alpha = 1, `soft_constraint=True`, do_mpc's default
+        penalty 1): long = rho C_m T / 2, long^2 + F_y^2 <= (alpha D)^2 per axle.  ellipse_radius = None takes the reference's
+        literal D_f = D_r = 1.0 (a radius of 1 N: unsatisfiable, which is presumably why the lines are commented out); a
+        pair (D_f, D_r) in newtons, e.g. the peak lateral forces F_N D, gives the physical constraint."""
         control_costs = np.asarray(control_costs, dtype=np.float64)
         assert control_costs.shape == (2, 1)  # controller.py:38
         if n_robust != 0:
@@ -134,6 +140,11 @@ class Controller:
             if not penalty_term_cons > 0:
                 raise ValueError("penalty_term_cons must be positive")
             o.soft_rho = float(penalty_term_cons)
+        if traction_ellipse:
+            if not ellipse_penalty > 0:
+                raise ValueError("ellipse_penalty must be positive")
+            Df, Dr = (p.D_f, p.D_r) if ellipse_radius is None else ellipse_radius
+            p.ell_penalty, p.ell_rho, p.ell_D_f, p.ell_D_r = float(ellipse_penalty), float(rho), float(alpha * Df), float(alpha * Dr)
         self.solver = BatchedMPC(model.track.tables, n_horizon=n_horizon, batch=batch, params=p, options=o, device=device)
         model._solver = self.solver  # (Simulator(model) runs the plant on the same handle)
         self.mpc = _MPC(self.solver)

@@ -170,6 +170,13 @@ class BatchedMPC:
                                       *(dptr(out[k]) for k in ("f", "J", "H", "cval", "cgrad", "cH", "gval", "ggrad", "gH"))))
         return out
 
+    def test_ellipse(self, x):
+        x = np.ascontiguousarray(np.asarray(x, float).reshape(-1, NX))
+        n = x.shape[0]
+        v, g, H = np.empty((n, 2)), np.empty((n, 2, 8)), np.empty((n, 2, 8, 8))
+        check(lib().ltompc_test_ellipse(self._h, n, dptr(x), dptr(v), dptr(g), dptr(H)))
+        return v, g, H
+
     def _x(self, x0):
         x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(-1, NX))
         if x0.shape[0] != self.B:

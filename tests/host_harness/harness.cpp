@@ -60,7 +60,8 @@ static void build_bounds(const ltompc_params& p, Bounds& b) {  // = build_bounds
     if (p.u_lb[i] > -LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = -1.0, b.ub_val[b.n_ub] = p.u_lb[i], b.n_ub++;
     if (p.u_ub[i] < LTOMPC_NO_BOUND) b.ub_idx[b.n_ub] = i, b.ub_sgn[b.n_ub] = +1.0, b.ub_val[b.n_ub] = p.u_ub[i], b.n_ub++;
   }
-  b.ni = b.n_ub + 2 * b.n_xb + NNL;
+  b.nel = p.ell_penalty > 0.0 ? NEL : 0;
+  b.ni = b.n_ub + 2 * b.n_xb + NNL + b.nel;
 }
 
 // run a thread-per-(k, b) kernel body over a grid of `threads` threads, 64 per block
@@ -77,7 +78,8 @@ int main(int argc, char** argv) {
   if (!f) return 2;
   int nt, N, B, any_bounds, ticks;
   double soft_rho;
-  if (fscanf(f, "%d %d %d %d %lf %d", &nt, &N, &B, &any_bounds, &soft_rho, &ticks) != 6) return 2;
+  double ell[4];
+  if (fscanf(f, "%d %d %d %d %lf %d %lf %lf %lf %lf", &nt, &N, &B, &any_bounds, &soft_rho, &ticks, &ell[0], &ell[1], &ell[2], &ell[3]) != 10) return 2;
   std::vector<double> tab((size_t)6 * nt), x0((size_t)8 * B);
   for (auto& v : tab) if (fscanf(f, "%lf", &v) != 1) return 2;
   for (auto& v : x0) if (fscanf(f, "%lf", &v) != 1) return 2;
@@ -86,6 +88,7 @@ int main(int argc, char** argv) {
   memset(&K, 0, sizeof K);
   default_params(&K.p), default_options(&K.o);
   K.o.soft_rho = soft_rho;
+  K.p.ell_penalty = ell[0], K.p.ell_rho = ell[1], K.p.ell_D_f = ell[2], K.p.ell_D_r = ell[3];
   build_bounds(K.p, K.bd);
   const int ni = K.bd.ni, Bp = (B + 63) / 64 * 64;
   double* d_tab = (double*)malloc(sizeof(double) * 6 * nt);  // exact size: ASan sees any look-up outside the tables
@@ -101,9 +104,10 @@ int main(int argc, char** argv) {
   const size_t n = N, bp = Bp;
   // EXACT sizes (no "+64" slack as in ltompc_create: an over-read past a buffer is an ASan error here)
   W.X = poisoned(8 * (n + 1) * bp), W.C = poisoned(8 * n * bp), W.U = poisoned(2 * n * bp), W.L1 = poisoned(8 * n * bp), W.L2 = poisoned(8 * n * bp);
-  W.T = poisoned((ni + NNL) * n * bp), W.NU = poisoned(ni * n * bp);
+  const size_t nel = K.bd.nel;
+  W.T = poisoned((ni + NNL + nel) * n * bp), W.NU = poisoned(ni * n * bp);
   W.dX = poisoned(8 * (n + 1) * bp), W.dC = poisoned(8 * n * bp), W.dU = poisoned(2 * n * bp), W.nL1 = poisoned(8 * n * bp), W.nL2 = poisoned(8 * n * bp);
-  W.dT = poisoned((ni + NNL) * n * bp), W.dNU = poisoned(ni * n * bp);
+  W.dT = poisoned((ni + NNL + nel) * n * bp), W.dNU = poisoned(ni * n * bp);
   W.QP = poisoned((size_t)QP_NF * (n + 1) * bp), W.RC = poisoned((size_t)RC_NF * (n + 1) * bp);
   W.RS = poisoned((size_t)RS_NF * n * bp), W.SP = poisoned((size_t)SP_NF * n * bp), W.LS = poisoned((size_t)3 * (K.o.n_linesearch + 1) * n * bp);
   W.x0 = poisoned(8 * bp), W.uprev = poisoned(2 * bp), W.st = poisoned((size_t)ST_NF * bp), W.filt = poisoned((size_t)2 * FILTER_MAX * bp);
@@ -113,7 +117,7 @@ int main(int argc, char** argv) {
   for (int b = 0; b < Bp; b++) act[b] = b;
   Launch la{act.data(), nact.data(), Bp, 0};
   std::vector<double> x(x0), u0((size_t)2 * B, 0.0), xn((size_t)8 * B);
-  const bool ref = !any_bounds;
+  const bool ref = !any_bounds, el = K.bd.nel > 0;
   for (int tick = 0; tick < ticks; tick++) {
     const int cold = tick == 0;
     grid64(B, [&] { k_load_x0(W, x.data(), nullptr, K.o.resto_sticky, cold ? 0 : 1); });
@@ -121,11 +125,11 @@ int main(int argc, char** argv) {
     grid64(N * Bp, [&] { k_init(&K, &W, cold); });
     memset(W.active, 0, sizeof(int) * (K.o.max_iter + 2)), W.ls_count[0] = W.ls_count[1] = 0;
     for (int it = 0;; it++) {
-      grid64(N * Bp, [&] { ref ? k_eval<BoundsRef>(&K, &W, la) : k_eval<BoundsAny>(&K, &W, la); });
+      grid64(N * Bp, [&] { el ? (ref ? k_eval<BoundsRef, true>(&K, &W, la) : k_eval<BoundsAny, true>(&K, &W, la)) : (ref ? k_eval<BoundsRef, false>(&K, &W, la) : k_eval<BoundsAny, false>(&K, &W, la)); });
       grid64(Bp, [&] { k_riccati(&K, &W, la, it); });
       if (it >= K.o.max_iter) break;
-      grid64(N * Bp, [&] { ref ? k_expand<BoundsRef>(&K, &W, la) : k_expand<BoundsAny>(&K, &W, la); });
-      grid64(N * Bp, [&] { ref ? k_linesearch<BoundsRef>(&K, &W, la, 0, Bp) : k_linesearch<BoundsAny>(&K, &W, la, 0, Bp); });
+      grid64(N * Bp, [&] { el ? (ref ? k_expand<BoundsRef, true>(&K, &W, la) : k_expand<BoundsAny, true>(&K, &W, la)) : (ref ? k_expand<BoundsRef, false>(&K, &W, la) : k_expand<BoundsAny, false>(&K, &W, la)); });
+      grid64(N * Bp, [&] { el ? (ref ? k_linesearch<BoundsRef, true>(&K, &W, la, 0, Bp) : k_linesearch<BoundsAny, true>(&K, &W, la, 0, Bp)) : (ref ? k_linesearch<BoundsRef, false>(&K, &W, la, 0, Bp) : k_linesearch<BoundsAny, false>(&K, &W, la, 0, Bp)); });
       auto pick = [&](int b, int phase) {  // the 8 lanes of instance b (k_pick), as 8 OS threads
         LtLaneGroup g;
         pthread_barrier_init(&g.bar, nullptr, 8);
@@ -137,7 +141,7 @@ int main(int argc, char** argv) {
       for (int b = 0; b < B; b++) pick(b, 0);
       if (K.o.n_linesearch > 1 && W.ls_count[0] > 0) {
         const int jw = W.ls_count[0];
-        grid64((K.o.n_linesearch - 1) * N * jw, [&] { ref ? k_linesearch<BoundsRef>(&K, &W, la, 1, jw) : k_linesearch<BoundsAny>(&K, &W, la, 1, jw); });
+        grid64((K.o.n_linesearch - 1) * N * jw, [&] { el ? (ref ? k_linesearch<BoundsRef, true>(&K, &W, la, 1, jw) : k_linesearch<BoundsAny, true>(&K, &W, la, 1, jw)) : (ref ? k_linesearch<BoundsRef, false>(&K, &W, la, 1, jw) : k_linesearch<BoundsAny, false>(&K, &W, la, 1, jw)); });
         for (int j = 0; j < jw; j++) pick(W.ls_list[j], 1);
       }
       grid64(N * Bp, [&] { k_update(&K, &W, la); });

@@ -828,3 +828,65 @@ def test_torque_vectoring_on_gpu(pkg, tables, orc, gpu_lib):
         xn = m.plant_step(x0, ref["u0"])
         assert np.abs(xn - oracle.plant_step(x0, ref["u0"])).max() < 1e-9
         m.close()
+
+
+def test_friction_ellipse_constraints_on_gpu(pkg, tables, orc, gpu_lib):
+    """params.ell_* (model.py:86-99 get_traction_ellipse_constraint, soft nl constraints the reference has commented out at
+    controller.py:72-74): hand-derived derivatives against the oracle's AD; solves (cold + 2 warm ticks, radius 0.8 F_N D, the
+    longitudinal scale rho = 5 of MX5.json) against the oracle: statuses, controls, iteration counts; the returned point satisfies
+    the KKT conditions of the NLP with the two extra soft constraints (independent torch evaluation); the constraints bind
+    (multipliers > 0) and change the controls.  The reference's literal radius D = 1.0 is accepted too (an NLP dominated by the
+    penalty: every tyre force of newtons violates it)."""
+    import nlp_reference as R
+    ell = (10.0, 5.0, 0.8 * 4905.0, 0.8 * 4905.0)
+    p = pkg.default_params(); p.ell_penalty, p.ell_rho, p.ell_D_f, p.ell_D_r = ell
+    po = orc.default_params(); po.ell_penalty, po.ell_rho, po.ell_D_f, po.ell_D_r = ell
+    oracle = orc.Oracle(tables.packed(), params=po)
+    n = 100
+    x, _ = _points(pkg, tables, n, seed=9)
+    x[:, 6] = np.random.default_rng(2).uniform(-0.5, 0.5, n); x[:, 7] = np.random.default_rng(3).uniform(-1, 1, n)
+    m = pkg.BatchedMPC(tables, 10, 1, params=p)
+    v, g, H = m.test_ellipse(x)
+    for i in range(n):
+        vo, go, Ho = oracle.ell_derivs(x[i])
+        assert np.abs(v[i] - vo).max() <= 1e-12 * (1 + np.abs(vo).max())
+        assert np.abs(g[i] - go).max() <= 1e-11 * (1 + np.abs(go).max())
+        assert np.abs(H[i] - Ho).max() <= 1e-10 * (1 + np.abs(Ho).max())
+    m.close()
+    B, N = 32, 20
+    x0 = pkg.sample_x0(tables, B, seed=29)
+    base = orc.Oracle(tables.packed()).solve(x0, N, nthreads=8)
+    o = pkg.default_options(); o.max_iter = 400
+    oracle.o.max_iter = 400
+    mpc = pkg.BatchedMPC(tables, N, B, params=p, options=o)
+    mpc.set_initial_guess(x0)
+    xx, ref, up = x0.copy(), None, np.zeros((B, 2))
+    for tick in range(3):
+        u = mpc.make_step(xx)
+        s = mpc.stats()
+        ref = oracle.solve(xx, N, up, ref, nthreads=8, prev_status=None if ref is None else ref["status"])
+        both = (s["status"] == 0) & (ref["status"] == 0)
+        assert (s["status"] == ref["status"]).mean() >= 0.9 and both.mean() >= 0.8, (tick, s["status"], ref["status"])
+        assert np.abs(u - ref["u0"])[both].max() < 1e-5, tick
+        assert (np.abs(s["iters"] - ref["iters"])[both] <= 3).mean() >= 0.85, tick
+        assert np.abs(s["obj"] - ref["obj"])[both].max() < 1e-6 * max(1.0, np.abs(ref["obj"][both]).max())
+        if tick == 0:
+            assert np.abs(ref["u0"] - base["u0"]).max() > 1e-3       # the constraints change the solutions ...
+            sol = mpc.iterate()
+            assert sol["NU"].shape[2] == 25 and sol["NU"][:, :-1, -2:].max() > 0.1   # ... and bind (elastic multipliers)
+            for b in np.where(both)[0][:4]:
+                k = R.kkt_residuals(sol, xx[b], np.zeros(2), tables, o.smooth_eps_min, int(b), ell=ell)
+                assert k["stationarity"] < 1e-6 and k["equality"] < 1e-7 and k["ineq_violation"] < 1e-7 and k["complementarity"] < 1e-6, k
+                assert k["ell_complementarity"] < 1e-6 and 0.0 <= k["min_ell_multiplier"] and k["max_ell_multiplier"] <= ell[0] + 1e-9, k
+                assert k["objective"] == pytest.approx(s["obj"][b], rel=1e-7, abs=1e-6)
+        xx, up = oracle.plant_step(xx, ref["u0"]), ref["u0"]
+    mpc.close()
+    # the reference's literal constants (alpha D = 1.0, rho = 1, do_mpc's default penalty 1): accepted, runs, finite
+    p1 = pkg.default_params(); p1.ell_penalty, p1.ell_rho, p1.ell_D_f, p1.ell_D_r = 1e-6, 1.0, 1.0, 1.0
+    m1 = pkg.BatchedMPC(tables, 10, 4, params=p1, options=o)
+    m1.set_initial_guess(x0[:4])
+    assert np.all(np.isfinite(m1.make_step(x0[:4])))
+    m1.close()
+    bad = pkg.default_params(); bad.ell_penalty, bad.ell_D_f = 1.0, 0.0
+    with pytest.raises(pkg.LtompcError):
+        pkg.BatchedMPC(tables, 10, 1, params=bad)

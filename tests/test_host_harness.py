@@ -27,11 +27,11 @@ def harness():
     return EXE
 
 
-def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2):
+def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2, ell=(0.0, 0.0, 0.0, 0.0)):
     prob = tmp_path / "problem.txt"
     tab = tables.packed()
     with open(prob, "w") as f:
-        f.write(f"{tab.shape[1]} {N} {x0.shape[0]} {any_bounds} {soft_rho!r} {ticks}\n")
+        f.write(f"{tab.shape[1]} {N} {x0.shape[0]} {any_bounds} {soft_rho!r} {ticks} {ell[0]!r} {ell[1]!r} {ell[2]!r} {ell[3]!r}\n")
         np.savetxt(f, tab.ravel()[None], fmt="%.17g")
         np.savetxt(f, x0.ravel()[None], fmt="%.17g")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
@@ -79,3 +79,16 @@ def test_device_code_soft_constraints_under_sanitizers(harness, tmp_path, orc, p
     ref = orc.Oracle(tables.packed(), options=o).solve(x0, N, nthreads=4)
     assert np.all(np.isfinite(res[0])) and np.array_equal(res[0][:, 1].astype(int), ref["status"])
     assert np.abs(res[0][:, 3:5] - ref["u0"]).max() < 1e-6
+
+
+def test_device_code_friction_ellipse_under_sanitizers(harness, tmp_path, orc, pkg, tables):
+    """The friction-ellipse constraints (params.ell_*; kernels instantiated with ELL) on the same harness, against the oracle."""
+    N = 6
+    x0 = pkg.sample_x0(tables, 4, seed=63)
+    ell = (10.0, 5.0, 0.8 * 4905.0, 0.8 * 4905.0)
+    res = _run(harness, tmp_path, tables, x0, N, ticks=1, ell=ell)
+    p = orc.default_params(); p.ell_penalty, p.ell_rho, p.ell_D_f, p.ell_D_r = ell
+    ref = orc.Oracle(tables.packed(), params=p).solve(x0, N, nthreads=4)
+    assert np.all(np.isfinite(res[0])) and np.array_equal(res[0][:, 1].astype(int), ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= 3 and np.abs(res[0][:, 3:5] - ref["u0"])[ok].max() < 1e-6

@@ -52,6 +52,8 @@ def test_controller_argument_checks(pkg):
         pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)), n_robust=1)
     with pytest.raises(ValueError):  # do_mpc's set_nl_cons(soft_constraint=True, penalty_term_cons=...) needs a positive penalty
         pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)), soft_constraint=True, penalty_term_cons=0.0)
+    with pytest.raises(ValueError):
+        pkg.Controller(model, np.reshape([1e-2, 1e-2], (-1, 1)), traction_ellipse=True, ellipse_penalty=0.0)
 
 
 def test_options_struct_matches_the_header(pkg, orc):
