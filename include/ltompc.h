@@ -181,6 +181,20 @@ int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status,
  * stream; the call returns after the last poll, the final u0 store may still be in flight on that stream. */
 int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev);
 
+/* Closed-loop rollout with FREE-RUNNING instances: every instance does n_ticks of the reference's loop body (src/mpc.py:140-153:
+ * u0 = make_step(x0); x0 = plant(x0, u0)), but an instance that has converged takes its plant step and starts its next tick
+ * inside the running batch instead of waiting for the slowest instance of the tick (no coupling exists between instances;
+ * with make_step 40 % of a tick is spent on the 4 % of instances that need many iterations).  Per instance the
+ * sequence of solves is exactly the one of make_step + plant_step in a loop: controls, statuses and iteration counts are
+ * bit-identical (tests/test_gpu_parity.py).  Starts from the handle's current guess / warm start like make_step.
+ *   x_dev: batch x 8 (device, in: states at tick 0, out: states after n_ticks); n_sub: RK4 sub-steps of the plant;
+ *   u_log_dev: batch x n_ticks x 2, status_log_dev, iters_log_dev: batch x n_ticks (device, out; any may be NULL).
+ * Synchronous.  Afterwards the handle holds every instance's last solution (warm start of a following make_step / rollout). */
+int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, double* u_log_dev, int* status_log_dev,
+                       int* iters_log_dev);
+/* interior-point iterations launched and kernel launches of the last rollout */
+int ltompc_rollout_info(ltompc_handle h, long long* iterations, long long* launches);
+
 /* Predicted trajectories of the last solve (do_mpc: mpc.opt_x_num['_x', k, 0, -1], ['_u', k, 0]).
  *   X: batch x (N+1) x 8, U: batch x N x 2 (host, out; either may be NULL). */
 int ltompc_get_prediction(ltompc_handle h, double* X, double* U);

@@ -7,13 +7,8 @@ namespace ltompc {
 // ------------------------------------------------------------------------------------------ k_init
 // Cold: do_mpc set_initial_guess (every state slot = x0, inputs 0, multipliers 0).  Warm: keep the previous
 // primal/dual solution un-shifted (do_mpc), node 0 := new x0.  Slacks t = max(-h, bound_push), nu = mu/t.
-__global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, int cold) {
-  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
-  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
-  int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  int b = tid % W.Bp, k = tid / W.Bp;
+__device__ __forceinline__ void d_init_slot(const Consts& K, const Work& W, const int k, const int b, const int cold) {
   const int N = W.N;
-  if (k >= N || b >= W.B) return;
   double x0[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) x0[i] = W.x0[(size_t)i * W.Bp + b];
@@ -63,10 +58,18 @@ __global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ W
     st[(size_t)ST_C00 * W.Bp + b] = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
     st[(size_t)ST_RHO * W.Bp + b] = rho, st[(size_t)ST_VIOL * W.Bp + b] = 0.0;
     for (int i = 0; i < SI_NF; i++)
-      if (i != SI_PREV && (i != SI_STICKY || cold)) W.si[(size_t)i * W.Bp + b] = 0;
+      if (i != SI_PREV && (i != SI_STICKY || cold) && i != SI_PHASE && i != SI_TICKS && i != SI_FINAL) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
     if (start_elastic) W.si[(size_t)SI_RESTO * W.Bp + b] = 1, W.si[(size_t)SI_NRESTO * W.Bp + b] = 1, W.si[(size_t)SI_STARTEL * W.Bp + b] = 1;
   }
+}
+__global__ void k_init(const Consts* __restrict__ Kp, const Work* __restrict__ Wp, int cold) {
+  const Consts& K = *Kp;  // K and W live in device memory: fields are fetched where they are used instead of
+  const Work& W = *Wp;    // occupying (spilled) SGPRs for the whole kernel
+  int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = tid % W.Bp, k = tid / W.Bp;
+  if (k >= W.N || b >= W.B) return;
+  d_init_slot(K, W, k, b, cold);
 }
 
 // ------------------------------------------------------------------------------------------ k_shift
@@ -208,10 +211,7 @@ __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restri
 // row-major (B x 8) user buffer -> [8][Bp] planes
 // (orig != nullptr: the instances are in packed order, slot b holds the caller's instance orig[b])
 // (sticky: options.resto_sticky, 0 = off; update = 0 when called for set_initial_guess, whose k_init resets the counter)
-__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* __restrict__ orig, int sticky, int update) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= W.B) return;
-  const size_t r = orig ? orig[b] : b;
+__device__ __forceinline__ void d_load_x0(const Work& W, const double* __restrict__ x0_rm, const int b, const size_t r, const int sticky, const int update) {
 #pragma unroll
   for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[r * 8 + i];
   const int prev = W.si[(size_t)SI_STATUS * W.Bp + b];
@@ -222,6 +222,11 @@ __global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* _
     const int c = W.si[(size_t)SI_STICKY * W.Bp + b];
     W.si[(size_t)SI_STICKY * W.Bp + b] = (prev == LTOMPC_STATUS_INFEASIBLE || jammed) ? sticky : (c > 0 ? c - 1 : 0);
   }
+}
+__global__ void k_load_x0(Work W, const double* __restrict__ x0_rm, const int* __restrict__ orig, int sticky, int update) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= W.B) return;
+  d_load_x0(W, x0_rm, b, orig ? orig[b] : b, sticky, update);
 }
 __global__ void k_zero_uprev(Work W) {
   int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -250,13 +255,9 @@ __global__ void k_status_counts(Work W, int* __restrict__ counts, unsigned long 
 }
 
 // plant: classical RK4 with n_sub sub-steps, zero-order-hold input (do_mpc Simulator / CVODES stand-in)
-__global__ void k_plant(Consts K, int B, const double* __restrict__ x, const double* __restrict__ u, double dt,
-                        int n_sub, double* __restrict__ xn) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  double y[8], uu[2] = {u[(size_t)b * 2], u[(size_t)b * 2 + 1]};
+__device__ __forceinline__ void d_plant(const Consts& K, const double* x, const double* uu, const double dt, const int n_sub, double* y) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) y[i] = x[(size_t)b * 8 + i];
+  for (int i = 0; i < 8; i++) y[i] = x[i];
   const double hs = dt / n_sub;
   for (int s = 0; s < n_sub; s++) {
     double k1[8], k2[8], k3[8], k4[8], z[8];
@@ -273,6 +274,15 @@ __global__ void k_plant(Consts K, int B, const double* __restrict__ x, const dou
 #pragma unroll
     for (int i = 0; i < 8; i++) y[i] += hs / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
   }
+}
+__global__ void k_plant(Consts K, int B, const double* __restrict__ x, const double* __restrict__ u, double dt,
+                        int n_sub, double* __restrict__ xn) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double xb[8], y[8], uu[2] = {u[(size_t)b * 2], u[(size_t)b * 2 + 1]};
+#pragma unroll
+  for (int i = 0; i < 8; i++) xb[i] = x[(size_t)b * 8 + i];
+  d_plant(K, xb, uu, dt, n_sub, y);
 #pragma unroll
   for (int i = 0; i < 8; i++) xn[(size_t)b * 8 + i] = y[i];
 }

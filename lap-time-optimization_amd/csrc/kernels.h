@@ -18,6 +18,7 @@
 //                 bookkeeping), k_update (z += alpha dz), k_step1 (the three fused, one workgroup per instance)
 //   aux_kernels.h k_init, k_shift, re-packing of the unfinished instances (k_pack_perm / k_pack move their data to the
 //                 front of the batch, k_compact re-packs the index list only), I/O, k_plant (RK4 plant step), test hooks
+//   rollout.h     k_roll_*: closed-loop rollout with free-running instances (ltompc_rollout_dev)
 //   velocity.h    k_velocity_profile: the forward / backward speed-profile passes of src/velocity.py
 #pragma once
 #include "layout.h"
@@ -27,3 +28,4 @@
 #include "aux_kernels.h"
 #include "eval8.h"
 #include "velocity.h"
+#include "rollout.h"

@@ -60,6 +60,8 @@ enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_S
              SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_RESTO, SI_REINIT, SI_NRESTO,
              SI_STICKY,   // option resto_sticky: solves for which the instance still starts in elastic mode (kept between make_steps)
              SI_STARTEL,  // this solve started in elastic mode
+             // closed-loop rollout (rollout.h): where the instance is in its tick cycle, ticks it still has to do, finished for good
+             SI_PHASE, SI_TICKS, SI_FINAL,
              SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
 
 struct Work {

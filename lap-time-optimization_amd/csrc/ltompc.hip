@@ -67,6 +67,10 @@ struct ltompc_solver {
   int cur_width = 0;  // instances in the launches being issued
   int cur_iter = 0;   // interior-point iteration the launches being issued belong to
   int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum (k_status_counts)
+  int* d_roll = nullptr;    // rollout: ring of 8 counters of instances that still have ticks to do
+  hipStream_t plant_stream = nullptr;  // rollout: the plant steps of converged instances run beside the solver
+  hipEvent_t roll_ev = nullptr;
+  long long roll_iterations = 0, roll_launches = 0;
   double ms_by_kernel[NKERN] = {};
   int launches_by_kernel[NKERN] = {};
   Consts* d_K = nullptr;  // device copies of K and W for the solver kernels
@@ -148,6 +152,42 @@ struct Launcher {
     return 0;
   }
 };
+
+// The kernels of one interior-point iteration over the instances of `la` (make_step and the closed-loop rollout share it).
+int launch_iteration(ltompc_solver* h, Launcher& L, const Launch& la, const int it, const int n_launch, const int ls_width, const bool ell,
+                     const bool riccati_only) {
+  const int N = h->N, np = la.n_pad;
+    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, ell ? (h->ref_eval ? k_eval<BoundsRef, true> : k_eval<BoundsAny, true>) : (h->ref_eval ? k_eval<BoundsRef, false> : k_eval<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
+    if (h->serial_riccati) {
+      if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
+    } else {
+      // measured: letting the stragglers retry inside a launch (max_sweeps 4 when n_launch <= 256) finishes them in
+      // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
+      const int max_sweeps = 1;
+      if (n_launch <= h->ric1_width) {
+        L.lds = ric1_lds_bytes(N);
+        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;  // one wavefront per instance
+      } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
+    }
+    if (riccati_only) return 0;  // (make_step's last pass: only finalises the statuses, MAX_ITER)
+    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, ell ? (h->ref_expand ? k_expand<BoundsRef, true> : k_expand<BoundsAny, true>) : (h->ref_expand ? k_expand<BoundsRef, false> : k_expand<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
+    if (n_launch <= h->step1_width) {
+      // one workgroup per instance does both line-search phases, the filter test and the update
+      L.block_threads = 320;
+      if (L.run(7, ell ? (h->ref_step1 ? k_step1<BoundsRef, true> : k_step1<BoundsAny, true>) : (h->ref_step1 ? k_step1<BoundsRef, false> : k_step1<BoundsAny, false>), n_launch * 320, h->d_K, h->d_W, la)) return -1;
+    } else {
+      const auto kls = ell ? (h->ref_ls ? k_linesearch<BoundsRef, true> : k_linesearch<BoundsAny, true>) : (h->ref_ls ? k_linesearch<BoundsRef, false> : k_linesearch<BoundsAny, false>);
+      if (L.run(3, kls, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
+      if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
+      if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
+        const int jw = np < ls_width ? np : ls_width;  // launch width of the second phase (longer lists are covered grid-stride)
+        if (L.run(3, kls, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
+        if (L.run(4, k_pick, jw * 8, h->d_K, h->d_W, la, 1)) return -1;
+      }
+      if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;
+    }
+  return 0;
+}
 
 int collect_profile(ltompc_solver* h) {
   for (size_t i = 0; i + 1 < h->ev_kind.size(); i++) {
@@ -334,7 +374,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
-  rc |= h->dalloc(&h->d_counts, 16);
+  rc |= h->dalloc(&h->d_counts, 16), rc |= h->dalloc(&h->d_roll, 8);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
@@ -378,6 +418,8 @@ int ltompc_destroy(ltompc_handle h) {
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->h_active) (void)hipHostFree(h->h_active);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->plant_stream) (void)hipStreamDestroy(h->plant_stream);
+  if (h->roll_ev) (void)hipEventDestroy(h->roll_ev);
   delete h;
   return 0;
 }
@@ -462,35 +504,11 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
     h->cur_iter = it;
     la.force_eval = force_eval_next ? 1 : 0;
     force_eval_next = false;
-    if (h->eval8 ? L.run(0, k_eval8, N * np * 8, h->d_K, h->d_W, la) : L.run(0, ell ? (h->ref_eval ? k_eval<BoundsRef, true> : k_eval<BoundsAny, true>) : (h->ref_eval ? k_eval<BoundsRef, false> : k_eval<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
-    if (h->serial_riccati) {
-      if (L.run(1, k_riccati, np, h->d_K, h->d_W, la, it)) return -1;
-    } else {
-      // measured: letting the stragglers retry inside a launch (max_sweeps 4 when n_launch <= 256) finishes them in
-      // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
-      const int max_sweeps = 1;
-      if (n_launch <= h->ric1_width) {
-        L.lds = ric1_lds_bytes(N);
-        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;  // one wavefront per instance
-      } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
+    {
+      const int rc = launch_iteration(h, L, la, it, n_launch, ls_width, ell, it >= h->max_iter);
+      if (rc < 0) return -1;
     }
-    if (it >= h->max_iter) break;  // this pass only finalised the statuses (MAX_ITER)
-    if (h->eval8 ? L.run(2, k_expand8, N * np * 8, h->d_K, h->d_W, la) : L.run(2, ell ? (h->ref_expand ? k_expand<BoundsRef, true> : k_expand<BoundsAny, true>) : (h->ref_expand ? k_expand<BoundsRef, false> : k_expand<BoundsAny, false>), N * np, h->d_K, h->d_W, la)) return -1;
-    if (n_launch <= h->step1_width) {
-      // one workgroup per instance does both line-search phases, the filter test and the update
-      L.block_threads = 320;
-      if (L.run(7, ell ? (h->ref_step1 ? k_step1<BoundsRef, true> : k_step1<BoundsAny, true>) : (h->ref_step1 ? k_step1<BoundsRef, false> : k_step1<BoundsAny, false>), n_launch * 320, h->d_K, h->d_W, la)) return -1;
-    } else {
-      const auto kls = ell ? (h->ref_ls ? k_linesearch<BoundsRef, true> : k_linesearch<BoundsAny, true>) : (h->ref_ls ? k_linesearch<BoundsRef, false> : k_linesearch<BoundsAny, false>);
-      if (L.run(3, kls, N * np, h->d_K, h->d_W, la, 0, np)) return -1;
-      if (L.run(4, k_pick, np * 8, h->d_K, h->d_W, la, 0)) return -1;  // 8 lanes per instance
-      if (h->K.o.n_linesearch > 1) {  // remaining step candidates, only for instances whose full step was rejected
-        const int jw = np < ls_width ? np : ls_width;  // launch width of the second phase (longer lists are covered grid-stride)
-        if (L.run(3, kls, (h->K.o.n_linesearch - 1) * N * jw, h->d_K, h->d_W, la, 1, jw)) return -1;
-        if (L.run(4, k_pick, jw * 8, h->d_K, h->d_W, la, 1)) return -1;
-      }
-      if (L.run(5, k_update, N * np, h->d_K, h->d_W, la)) return -1;
-    }
+    if (it >= h->max_iter) break;  // that pass only finalised the statuses (MAX_ITER)
     if ((it + 1) % h->poll_every == 0) {
       if (L.close()) return -1;
       HIPCHECK(hipMemcpyAsync(h->h_active, h->W.active + it, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -590,6 +608,93 @@ int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation) {
     // (meaningful while the elastic variables exist: 0 once the solve is back on the hard constraints)
     if (violation) violation[b] = st[(size_t)ST_RHO * h->Bp + b] > 0.0 ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
   }
+  return 0;
+}
+
+// Closed-loop rollout with free-running instances (rollout.h): n_ticks of [make_step -> plant step] per instance.
+int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, double* u_log_dev, int* status_log_dev, int* iters_log_dev) {
+  if (!h || !x_dev) return fail("ltompc_rollout: null argument");
+  if (n_ticks < 1 || n_sub < 1) return fail("ltompc_rollout: n_ticks and n_sub must be >= 1");
+  if (h->K.o.warm_shift) return fail("ltompc_rollout: options.warm_shift is not supported by the rollout");
+  if (h->eval8) return fail("ltompc_rollout: latency-mode handles (8-lanes-per-slot kernels) are not supported by the rollout");
+  HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;  // the rollout works in the caller's order (index-list compaction only)
+  if (!h->plant_stream) {
+    HIPCHECK(hipStreamCreateWithFlags(&h->plant_stream, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&h->roll_ev, hipEventDisableTiming));
+  }
+  const int B = h->B, N = h->N, Bp = h->Bp;
+  const bool ell = h->K.bd.nel > 0;
+  const int prof = h->profiling;
+  h->profiling = 0;  // (per-launch events are a make_step facility)
+  Launcher L{h};
+  hipLaunchKernelGGL(k_roll_begin, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, n_ticks);
+  if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
+  HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, 2 * sizeof(int), h->stream));
+  int cur = 0, n_launch = B;
+  hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_act[0], h->d_nact[0], B);
+  Launch la{};
+  auto set_launch = [&](int n) {
+    n_launch = n;
+    la.act = (gptr<const int>)h->d_act[cur], la.nact = (gptr<const int>)h->d_nact[cur], la.n_pad = (n + 63) / 64 * 64;
+  };
+  set_launch(B);
+  int ls_width = h->ls_width_env ? h->ls_width_env : 512;
+  const long long it_cap = (long long)n_ticks * ((long long)h->max_iter + 8) + 64;  // every instance finishes every solve within max_iter + 1 passes
+  const int ring = h->max_iter + 2;
+  long long it = 0;
+  bool first = true;
+  int rc = 0;
+  for (;; it++) {
+    const int np = la.n_pad, slot = (int)(it % 8);
+    HIPCHECK(hipMemsetAsync(h->d_roll + slot, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL(k_roll_mark, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, (const double*)x_dev, h->K.o.resto_sticky,
+                       (first && h->cold_next) ? 1 : 0);  // (after set_initial_guess there is no solve before this one to take stock of)
+    hipLaunchKernelGGL(k_roll_init, dim3((N * np + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, la, (first && h->cold_next) ? 1 : 0);
+    la.force_eval = 0;
+    if (launch_iteration(h, L, la, (int)(it % ring), n_launch, ls_width, ell, false) < 0) { rc = -1; break; }
+    hipLaunchKernelGGL(k_roll_finish, dim3((np + 63) / 64), dim3(64), 0, h->stream, h->W, la, u_log_dev, status_log_dev, iters_log_dev, n_ticks,
+                       h->d_roll + slot);
+    // the plant steps of the instances that have just converged: second stream, after this iteration's k_roll_finish
+    HIPCHECK(hipEventRecord(h->roll_ev, h->stream));
+    HIPCHECK(hipStreamWaitEvent(h->plant_stream, h->roll_ev, 0));
+    hipLaunchKernelGGL(k_roll_plant, dim3((B + 63) / 64), dim3(64), 0, h->plant_stream, h->K, h->W, x_dev, h->K.o.t_step, n_sub);
+    first = false;
+    if ((it + 1) % h->poll_every == 0) {
+      HIPCHECK(hipMemcpyAsync(h->h_active, h->d_roll + slot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipStreamSynchronize(h->stream));
+      const int n_left = h->h_active[0];  // instances that still have ticks to do (counted before this iteration's plant steps)
+      if (h->ls_width_env == 0) {
+        const int last = h->h_active[1];
+        ls_width = std::min(std::max(64, (last + last / 2 + 63) / 64 * 64), 2048);
+      }
+      if (n_left == 0) break;
+      if (it >= it_cap) { rc = fail("ltompc_rollout: iteration cap reached (internal error)"); break; }
+      if (h->compaction && n_left <= (h->pack_num * n_launch) / 8) {
+        // instances that have done all their ticks leave the launches (index list only: their data stays where it is)
+        hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, h->stream, h->d_act[cur], h->d_nact[cur], h->W.si + (size_t)SI_FINAL * Bp,
+                           h->d_act[cur ^ 1], h->d_nact[cur ^ 1]);
+        cur ^= 1;
+        // (an instance can turn FINAL on the plant stream after this count: the list may keep it one round longer, harmless)
+        set_launch(n_left);
+      }
+    }
+  }
+  HIPCHECK(hipStreamSynchronize(h->plant_stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  HIPCHECK(hipGetLastError());
+  h->profiling = prof;
+  h->cold_next = false;
+  h->roll_iterations = it + 1, h->roll_launches = L.launches;
+  h->last_iterations = (int)std::min<long long>(it + 1, 1 << 30);
+  return rc;
+}
+
+int ltompc_rollout_info(ltompc_handle h, long long* iterations, long long* launches) {
+  if (!h) return fail("null handle");
+  if (iterations) *iterations = h->roll_iterations;
+  if (launches) *launches = h->roll_launches;
   return 0;
 }
 

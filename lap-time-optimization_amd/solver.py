@@ -63,6 +63,14 @@ class BatchedMPC:
     def make_step_dev(self, x0_ptr: int, u0_ptr: int):
         check(lib().ltompc_make_step_dev(self._h, C.c_void_p(x0_ptr), C.c_void_p(u0_ptr)))
 
+    def rollout_dev(self, x_ptr: int, n_ticks: int, n_sub: int = 400, u_log_ptr: int = 0, status_log_ptr: int = 0, iters_log_ptr: int = 0):
+        """Closed-loop rollout with free-running instances (ltompc_rollout_dev): n_ticks of make_step + plant step per instance."""
+        check(lib().ltompc_rollout_dev(self._h, C.c_void_p(x_ptr), int(n_ticks), int(n_sub), C.c_void_p(u_log_ptr or None),
+                                       C.c_void_p(status_log_ptr or None), C.c_void_p(iters_log_ptr or None)))
+        it, ln = C.c_longlong(), C.c_longlong()
+        check(lib().ltompc_rollout_info(self._h, C.byref(it), C.byref(ln)))
+        return dict(iterations=it.value, launches=ln.value)
+
     def plant_step_dev(self, x_ptr: int, u_ptr: int, xn_ptr: int, n_sub: int = 400):
         check(lib().ltompc_plant_step_dev(self._h, C.c_void_p(x_ptr), C.c_void_p(u_ptr), int(n_sub), C.c_void_p(xn_ptr)))
 

@@ -890,3 +890,47 @@ def test_friction_ellipse_constraints_on_gpu(pkg, tables, orc, gpu_lib):
     bad = pkg.default_params(); bad.ell_penalty, bad.ell_D_f = 1.0, 0.0
     with pytest.raises(pkg.LtompcError):
         pkg.BatchedMPC(tables, 10, 1, params=bad)
+
+
+def test_rollout_with_free_running_instances_is_the_synchronous_loop(pkg, tables, gpu_lib):
+    """ltompc_rollout_dev: every instance does K ticks of make_step + plant step, but converged instances go on to their next tick
+    inside the running batch (no lockstep between instances).  Controls, statuses, iteration counts and final states are
+    bit-identical to the synchronous loop, from a cold start and continuing from a warm handle; the batch contains instances that
+    go through the restoration phase; both the wide path (with index compaction at the end) and the narrow kernels are exercised."""
+    import torch
+    dev = torch.device("cuda", 0)
+    for B, N, K in ((700, 10, 7), (48, 20, 5)):
+        x0 = pkg.sample_x0(tables, B, seed=71)
+        x0[0] = STALL_STATES[20][0]
+        o = pkg.default_options(); o.latency_mode, o.max_iter, o.resto_sticky = 2, 300, 2
+        sync, roll = pkg.BatchedMPC(tables, N, B, options=o), pkg.BatchedMPC(tables, N, B, options=o)
+        xs = x0.copy()
+        sync.set_initial_guess(xs)
+        U, S, I = [], [], []
+        for t in range(2 * K):
+            u = sync.make_step(xs)
+            st = sync.stats()
+            U.append(u.copy()), S.append(st["status"].copy()), I.append(st["iters"].copy())
+            xs = sync.plant_step(xs, u, 50)
+        U, S, I = np.stack(U, 1), np.stack(S, 1), np.stack(I, 1)
+        xr = torch.from_numpy(x0).to(dev)
+        roll.set_initial_guess_dev(xr.data_ptr())
+        torch.cuda.synchronize(dev)
+        for part in range(2):   # cold start, then a second rollout that continues from the warm handle
+            ul = torch.zeros(B, K, 2, dtype=torch.float64, device=dev)
+            sl = torch.full((B, K), -1, dtype=torch.int32, device=dev)
+            il = torch.zeros(B, K, dtype=torch.int32, device=dev)
+            info = roll.rollout_dev(xr.data_ptr(), K, 50, ul.data_ptr(), sl.data_ptr(), il.data_ptr())
+            sel = slice(part * K, (part + 1) * K)
+            assert np.array_equal(ul.cpu().numpy(), U[:, sel]), (B, part)
+            assert np.array_equal(sl.cpu().numpy(), S[:, sel]) and np.array_equal(il.cpu().numpy(), I[:, sel]), (B, part)
+            # fewer passes than the synchronous loop needs launches: nobody waits for the slowest instance of a tick
+            assert info["iterations"] >= int((I[:, sel].sum(1) + K).max())
+        assert np.array_equal(xr.cpu().numpy(), xs)
+        assert np.array_equal(roll.stats()["status"], S[:, -1])   # the handle holds the last solves, like after make_step
+        sync.close(); roll.close()
+    o = pkg.default_options(); o.latency_mode = 1
+    m = pkg.BatchedMPC(tables, 10, 4, options=o)
+    with pytest.raises(pkg.LtompcError):
+        m.rollout_dev(torch.zeros(4, 8, dtype=torch.float64, device=dev).data_ptr(), 2, 50)   # latency-mode handles: not supported
+    m.close()
