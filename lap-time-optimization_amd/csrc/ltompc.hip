@@ -632,6 +632,7 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
   if (h->cold_next) hipLaunchKernelGGL(k_zero_uprev, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W);
   HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, 2 * sizeof(int), h->stream));
   int cur = 0, n_launch = B;
+  h->history.clear();
   hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_act[0], h->d_nact[0], B);
   Launch la{};
   auto set_launch = [&](int n) {
@@ -665,6 +666,7 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
       HIPCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
       const int n_left = h->h_active[0];  // instances that still have ticks to do (counted before this iteration's plant steps)
+      h->history.push_back((int)it), h->history.push_back(n_left), h->history.push_back(n_launch);
       if (h->ls_width_env == 0) {
         const int last = h->h_active[1];
         ls_width = std::min(std::max(64, (last + last / 2 + 63) / 64 * 64), 2048);

@@ -772,6 +772,13 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   // (read once: a global load inside the stage loop would wait, on vmcnt, for the RC stores of the previous stage)
   const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
   mu = __shfl(mu, 8 * i);  // the column lanes (g > 0) do real work here: give them the live lane's barrier parameter
+  // lane constants of the stage: which element of Huu / gu the lane forms (c1, d1), and what it stores
+  const int c1 = (g >> 1) & 1, d1 = g & 1;
+  const double r2c = c1 ? r2[1] : r2[0], r2d = d1 ? r2[1] : r2[0];
+  const int ofld = g == 0 ? RC_Pxv + i * 2 : (g == 1 ? RC_Pxv + i * 2 + 1 : (g == 2 ? RC_pp + i : (g == 3 ? RC_K + i : (g == 4 ? RC_K + 8 + i : (g == 5 ? RC_Kv + i : RC_kff + i)))));
+  const int ofld_p = RC_P + sidx(i, g);
+  const bool o_gain = g == 3 || g == 4 || (g == 5 && i < 4) || (g == 6 && i < 2);  // K, Kv, kff: every stage
+  const bool o_cost = g < 3;                                                        // Pxv, p: stages k > 0
   for (int sweep = 0;; sweep++) {
     delta_w = __shfl(delta_w, 8 * i);  // ... and its regularisation
     bool ok = true;
@@ -789,6 +796,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
     }
     WAVE_SYNC();
     L.Pxv[i * 2] = 0.0, L.Pxv[i * 2 + 1] = 0.0;
+    const bool live_w = __any(live);  // (one instance per wavefront: its column lanes store too)
 #pragma unroll 1
     for (int k = N - 1; k >= 0; k--) {
       Stage1Regs cur;
@@ -813,13 +821,16 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       if (g < 2) L.PB[i * 2 + g] = pb;
       L.Pb[i] = Pbi;
       WAVE_SYNC();
-      // 2. element (i, g) of Hxx, row i of Hux^T, gx_i
-      double Ai[8], PAg[8], PAi[8], B0[8], B1[8], X0[8], X1[8], Pbv[8];
+      // 2. element (i, g) of Hxx, row i of Hux^T, gx_i; the operands of the lane's element of Huu / gu (step 3) are
+      //    fetched here as well, with the lane's own column offsets (c1, d1) - selecting them from B0 / B1 / X0 / X1
+      //    costs two v_cndmask per double, 130 VALU instructions per stage
+      double Ai[8], PAg[8], PAi[8], B0[8], B1[8], X0[8], X1[8], Pbv[8], Bc[8], Xc[8], Xd[8], PBd[8];
 #pragma unroll
       for (int l = 0; l < 8; l++) {
         Ai[l] = qk[QP_A + l * 8 + i], PAg[l] = L.PA[l * 8 + g], PAi[l] = L.PA[l * 8 + i];
         B0[l] = qk[QP_B + l * 2], B1[l] = qk[QP_B + l * 2 + 1], X0[l] = L.Pxv[l * 2], X1[l] = L.Pxv[l * 2 + 1];
         Pbv[l] = L.Pb[l];
+        Bc[l] = qk[QP_B + l * 2 + c1], Xc[l] = L.Pxv[l * 2 + c1], Xd[l] = L.Pxv[l * 2 + d1], PBd[l] = L.PB[l * 2 + d1];
       }
       double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
 #pragma unroll
@@ -832,31 +843,21 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
         gx += ali * Pbv[l];
       }
       // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles.
-      //    Both sums are formed by every lane with selected operands (no divergent branches, no run-time indices into
-      //    register arrays: those would live in scratch, and a scratch reload waits for the RC stores of the stage before)
+      //    Both sums are formed by every lane (no divergent branches, no run-time indices into register arrays: those
+      //    would live in scratch, and a scratch reload waits for the RC stores of the stage before); Bg = column d1 of B
       double he;
       {
-        const bool c1 = (g >> 1) & 1, d1 = g & 1;
         const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);     // Rm[sidx(c, d)]
         const double pvv = c1 ? (d1 ? Pvv[3] : Pvv[2]) : (d1 ? Pvv[1] : Pvv[0]);  // Pvv[c * 2 + d]
-        double PBd[8];
-#pragma unroll
-        for (int l = 0; l < 8; l++) PBd[l] = L.PB[l * 2 + (g & 1)];
         double s = rm + pvv;
 #pragma unroll
-        for (int l = 0; l < 8; l++) {
-          const double Bc = c1 ? B1[l] : B0[l], Bd = d1 ? B1[l] : B0[l], Xc = c1 ? X1[l] : X0[l], Xd = d1 ? X1[l] : X0[l];
-          s += Bc * PBd[l] + Bc * Xd + Xc * Bd;
-        }
+        for (int l = 0; l < 8; l++) s += Bc[l] * PBd[l] + Bc[l] * Xd[l] + Xc[l] * Bg[l];
         double heH = s;
-        if (c1 == d1) heH += (c1 ? r2[1] : r2[0]) + delta_w;
+        if (c1 == d1) heH += r2c + delta_w;
         // gu[c], c = g & 1
-        double sg = (d1 ? rr[1] : rr[0]) + (d1 ? r2[1] : r2[0]) * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);
+        double sg = (d1 ? rr[1] : rr[0]) + r2d * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);
 #pragma unroll
-        for (int l = 0; l < 8; l++) {
-          const double Bc = d1 ? B1[l] : B0[l], Xc = d1 ? X1[l] : X0[l];
-          sg += Bc * Pbv[l] + Xc * bl[l];
-        }
+        for (int l = 0; l < 8; l++) sg += Bg[l] * Pbv[l] + Xd[l] * bl[l];
         he = g < 4 ? heH : (g < 6 ? sg : 0.0);
       }
       double Huu[4], gu[2];
@@ -891,27 +892,34 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       }
       L.P[i * 8 + g] = pn;
       WAVE_SYNC();
+      // row i of the symmetrised P for the next stage: row and column fetched in one batch, then combined (written as
+      // one conditional expression per element the compiler made eight basic blocks of it, each waiting for its own loads)
+      double Pr[8], Pc[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? L.P[i * 8 + j] : 0.5 * (L.P[i * 8 + j] + L.P[j * 8 + i]);
-      L.Pxv[i * 2] = pxv[0], L.Pxv[i * 2 + 1] = pxv[1];
-      if (g == 0) {  // the gains stay in LDS for the forward rollout (same numbers in all column lanes)
-        S.kk[k * 22 + i] = Kc[0], S.kk[k * 22 + 8 + i] = Kc[1];
-        if (i < 4) S.kk[k * 22 + 16 + i] = Kv[i];
-        if (i < 2) S.kk[k * 22 + 20 + i] = kff[i];
+      for (int j = 0; j < 8; j++) Pr[j] = L.P[i * 8 + j], Pc[j] = L.P[j * 8 + i];
+      double Pt = L.P[g * 8 + i];  // transposed partner of the lane's own element
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(Pr[0]), "+v"(Pr[1]), "+v"(Pr[2]), "+v"(Pr[3]), "+v"(Pr[4]), "+v"(Pr[5]), "+v"(Pr[6]), "+v"(Pr[7]));
+      asm volatile("" : "+v"(Pc[0]), "+v"(Pc[1]), "+v"(Pc[2]), "+v"(Pc[3]), "+v"(Pc[4]), "+v"(Pc[5]), "+v"(Pc[6]), "+v"(Pc[7]), "+v"(Pt));
+#endif
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const double sy = 0.5 * (Pr[j] + Pc[j]);
+        Prow[j] = (j == i) ? Pr[j] : sy;
       }
-      if (live) {
-        PG(W.RC, RC_K + i, k, RC_NF) = Kc[0], PG(W.RC, RC_K + 8 + i, k, RC_NF) = Kc[1];
-        // (selected, not indexed: a register array indexed by the lane's row lives in scratch memory, and a scratch reload
-        //  waits for the global stores issued before it - vmcnt counts both)
-        if (i < 4) PG(W.RC, RC_Kv + i, k, RC_NF) = i == 0 ? Kv[0] : (i == 1 ? Kv[1] : (i == 2 ? Kv[2] : Kv[3]));
-        if (i < 2) PG(W.RC, RC_kff + i, k, RC_NF) = i == 0 ? kff[0] : kff[1];
-        if (k > 0) {
-#pragma unroll
-          for (int j = 0; j < 8; j++)
-            if (j <= i) PG(W.RC, RC_P + sidx(i, j), k, RC_NF) = Prow[j];
-          PG(W.RC, RC_Pxv + i * 2, k, RC_NF) = pxv[0], PG(W.RC, RC_Pxv + i * 2 + 1, k, RC_NF) = pxv[1];
-          PG(W.RC, RC_pp + i, k, RC_NF) = ppi;
-        }
+      L.Pxv[i * 2] = pxv[0], L.Pxv[i * 2 + 1] = pxv[1];
+      // Stores: one element per lane.  Lane (g, i) holds element (i, g) of P (same expression as Prow[g] of row i);
+      // the remaining words of the stage go out through the lanes g = 0..6 of every row (all column lanes of a row hold the
+      // same K, Kv, kff, Pxv, p): two store instructions per stage instead of fourteen conditional ones
+      const double sy_own = 0.5 * (pn + Pt);
+      const double psym = (g == i) ? pn : sy_own;
+      const double Kvi = i == 0 ? Kv[0] : (i == 1 ? Kv[1] : (i == 2 ? Kv[2] : Kv[3]));
+      const double kfi = i == 0 ? kff[0] : kff[1];
+      const double oval = g == 0 ? pxv[0] : (g == 1 ? pxv[1] : (g == 2 ? ppi : (g == 3 ? Kc[0] : (g == 4 ? Kc[1] : (g == 5 ? Kvi : kfi)))));
+      if (o_gain) S.kk[k * 22 + ofld] = oval;  // the gains stay in LDS for the forward rollout (kk offsets = RC fields)
+      if (live_w) {
+        if (o_gain || (o_cost && k > 0)) PG(W.RC, ofld, k, RC_NF) = oval;
+        if (g <= i && k > 0) PG(W.RC, ofld_p, k, RC_NF) = psym;
       }
     }
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
