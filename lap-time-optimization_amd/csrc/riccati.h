@@ -480,41 +480,42 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
 #define LA(x) q[(QP_A + (x)) * 8 + g]
 #define LB(x) q[(QP_B + (x)) * 8 + g]
 #define Lb(x) q[(QP_b + (x)) * 8 + g]
-      // 1. row i of P A, P B, P b + p
+      // 1. row i of P A, P B, P b + p.  Operands are pulled from LDS into registers in batches and then used (here: four
+      //    rows of A, B, b at a time, 44 reads in flight): read where they are used, the compiler kept two or three reads
+      //    in flight and a lone wavefront paid most of the LDS latency of every one of the ~250 reads of a stage
       double PAr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, PBr[2] = {0, 0}, Pbi = ppi;
+      double Bm[16], bl[8];  // B_k and b_k stay in registers for steps 2 and 3
 #pragma unroll
-      for (int l = 0; l < 8; l++) {
+      for (int h = 0; h < 2; h++) {
+        double a[32];
 #pragma unroll
-        for (int j = 0; j < 8; j++) PAr[j] += Prow[l] * LA(l * 8 + j);
-        PBr[0] += Prow[l] * LB(l * 2), PBr[1] += Prow[l] * LB(l * 2 + 1);
-        Pbi += Prow[l] * Lb(l);
+        for (int l = 0; l < 4; l++) {
+#pragma unroll
+          for (int j = 0; j < 8; j++) a[l * 8 + j] = LA((h * 4 + l) * 8 + j);
+          Bm[(h * 4 + l) * 2] = LB((h * 4 + l) * 2), Bm[(h * 4 + l) * 2 + 1] = LB((h * 4 + l) * 2 + 1), bl[h * 4 + l] = Lb(h * 4 + l);
+        }
+#pragma unroll
+        for (int l = 0; l < 4; l++) {
+          const double pl = Prow[h * 4 + l];
+#pragma unroll
+          for (int j = 0; j < 8; j++) PAr[j] += pl * a[l * 8 + j];
+          PBr[0] += pl * Bm[(h * 4 + l) * 2], PBr[1] += pl * Bm[(h * 4 + l) * 2 + 1];
+          Pbi += pl * bl[h * 4 + l];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = PAr[j];
       L.PB[i * 2][g] = PBr[0], L.PB[i * 2 + 1][g] = PBr[1], L.Pb[i][g] = Pbi;
       WAVE_SYNC();
-      // 2. row i of Hxx = Q + A^T (P A), of Hux^T, and gx_i
-      double Hxx[8], Hxu[2], gx = qi;
-#pragma unroll
-      for (int j = 0; j < 8; j++) Hxx[j] = Qrow[j];
-      Hxu[0] = Scol[0], Hxu[1] = Scol[1];
+      // 3. (before 2: its operands are few, and the division that follows it can overlap the products of step 2)
+      //    Huu, gu (same numbers in the 8 lanes of an instance)
+      double Xm[16], PBm[16], Pbv[8];
 #pragma unroll
       for (int l = 0; l < 8; l++) {
-        double ali = LA(l * 8 + i);
-#pragma unroll
-        for (int j = 0; j < 8; j++) Hxx[j] += ali * L.PA[l * 8 + j][g];
-        double pali = L.PA[l * 8 + i][g];
-        Hxu[0] += LB(l * 2) * pali + L.Pxv[l * 2][g] * ali;
-        Hxu[1] += LB(l * 2 + 1) * pali + L.Pxv[l * 2 + 1][g] * ali;
-        gx += ali * L.Pb[l][g];
+        Xm[l * 2] = L.Pxv[l * 2][g], Xm[l * 2 + 1] = L.Pxv[l * 2 + 1][g];
+        PBm[l * 2] = L.PB[l * 2][g], PBm[l * 2 + 1] = L.PB[l * 2 + 1][g];
+        Pbv[l] = L.Pb[l][g];
       }
-      // (the next stage block is requested here: its 27 registers per lane are live for half a stage only)
-      {
-        const double* src = &PG(W.QP, i, kn, QP_NF);
-#pragma unroll
-        for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
-      }
-      // 3. Huu, gu (same numbers in the 8 lanes of an instance)
       double Huu[4], gu[2];
 #pragma unroll
       for (int c = 0; c < 2; c++) {
@@ -523,14 +524,51 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
           double s = Rm[sidx(c, d)] + Pvv[c * 2 + d];
 #pragma unroll
           for (int l = 0; l < 8; l++)
-            s += LB(l * 2 + c) * L.PB[l * 2 + d][g] + LB(l * 2 + c) * L.Pxv[l * 2 + d][g] + L.Pxv[l * 2 + c][g] * LB(l * 2 + d);
+            s += Bm[l * 2 + c] * PBm[l * 2 + d] + Bm[l * 2 + c] * Xm[l * 2 + d] + Xm[l * 2 + c] * Bm[l * 2 + d];
           Huu[c * 2 + d] = s;
         }
         Huu[c * 2 + c] += r2[c] + delta_w;
         double s = rr[c] + r2[c] * (uk[c] - vk[c]) + pv[c];
 #pragma unroll
-        for (int l = 0; l < 8; l++) s += LB(l * 2 + c) * L.Pb[l][g] + L.Pxv[l * 2 + c][g] * Lb(l);
+        for (int l = 0; l < 8; l++) s += Bm[l * 2 + c] * Pbv[l] + Xm[l * 2 + c] * bl[l];
         gu[c] = s;
+      }
+      // 2. row i of Hxx = Q + A^T (P A), of Hux^T, and gx_i
+      double Hxx[8], Hxu[2], gx = qi;
+#pragma unroll
+      for (int j = 0; j < 8; j++) Hxx[j] = Qrow[j];
+      Hxu[0] = Scol[0], Hxu[1] = Scol[1];
+      {
+        double Ai[8], PAi[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) Ai[l] = LA(l * 8 + i), PAi[l] = L.PA[l * 8 + i][g];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          double pa[32];
+#pragma unroll
+          for (int l = 0; l < 4; l++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) pa[l * 8 + j] = L.PA[(h * 4 + l) * 8 + j][g];
+#pragma unroll
+          for (int l = 0; l < 4; l++) {
+            const double ali = Ai[h * 4 + l];
+#pragma unroll
+            for (int j = 0; j < 8; j++) Hxx[j] += ali * pa[l * 8 + j];
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          const double ali = Ai[l], pali = PAi[l];
+          Hxu[0] += Bm[l * 2] * pali + Xm[l * 2] * ali;
+          Hxu[1] += Bm[l * 2 + 1] * pali + Xm[l * 2 + 1] * ali;
+          gx += ali * Pbv[l];
+        }
+      }
+      // (the next stage block is requested here: its 27 registers per lane are live for half a stage only)
+      {
+        const double* src = &PG(W.QP, i, kn, QP_NF);
+#pragma unroll
+        for (int j = 0; j < NPF; j++) pf[j] = src[j * 64];
       }
 #undef LA
 #undef LB
@@ -566,8 +604,19 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
 #pragma unroll
       for (int j = 0; j < 8; j++) L.PA[i * 8 + j][g] = Pn[j];
       WAVE_SYNC();
+      {
+        double Pt[8];  // column i of the new P: one batch of reads (as one conditional expression per element: eight basic blocks, each waiting for its own load)
 #pragma unroll
-      for (int j = 0; j < 8; j++) Prow[j] = (j == i) ? Pn[j] : 0.5 * (Pn[j] + L.PA[j * 8 + i][g]);
+        for (int j = 0; j < 8; j++) Pt[j] = L.PA[j * 8 + i][g];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(Pt[0]), "+v"(Pt[1]), "+v"(Pt[2]), "+v"(Pt[3]), "+v"(Pt[4]), "+v"(Pt[5]), "+v"(Pt[6]), "+v"(Pt[7]));
+#endif
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const double sy = 0.5 * (Pn[j] + Pt[j]);
+          Prow[j] = (j == i) ? Pn[j] : sy;
+        }
+      }
       L.Pxv[i * 2][g] = pxv[0], L.Pxv[i * 2 + 1][g] = pxv[1];  // read after the next stage's first barrier
       // the stage block fetched above goes to the other buffer (last read one stage ago), BEFORE this stage's stores
       // are issued: waiting for the loads then does not wait for the stores
