@@ -67,9 +67,13 @@ struct ltompc_solver {
   int cur_width = 0;  // instances in the launches being issued
   int cur_iter = 0;   // interior-point iteration the launches being issued belong to
   int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum (k_status_counts)
-  int* d_roll = nullptr;    // rollout: ring of 8 counters of instances that still have ticks to do
-  hipStream_t plant_stream = nullptr;  // rollout: the plant steps of converged instances run beside the solver
-  hipEvent_t roll_ev = nullptr;
+  // rollout: per pass (ring slot) the number of instances that still have ticks to do and the list of the instances that
+  // converged in it; their plant steps run beside the solver, on a few streams in turn (a plant step takes ~3 narrow passes)
+  static constexpr int ROLL_RING = 16, ROLL_PLANTS = 4;
+  int* d_roll = nullptr;    // [ROLL_RING][2]: instances not FINAL, length of the plant list
+  int* d_plist = nullptr;   // [ROLL_RING][Bp]
+  hipStream_t plant_streams[ROLL_PLANTS] = {};
+  hipEvent_t ev_fin[ROLL_RING] = {}, ev_done[ROLL_RING] = {};  // pass finished (solver stream) / its plant steps done (plant stream)
   long long roll_iterations = 0, roll_launches = 0;
   double ms_by_kernel[NKERN] = {};
   int launches_by_kernel[NKERN] = {};
@@ -374,7 +378,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
-  rc |= h->dalloc(&h->d_counts, 16), rc |= h->dalloc(&h->d_roll, 8);
+  rc |= h->dalloc(&h->d_counts, 16), rc |= h->dalloc(&h->d_roll, 2 * ltompc_solver::ROLL_RING);
+  rc |= h->dalloc(&h->d_plist, (size_t)ltompc_solver::ROLL_RING * h->Bp);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
   if (rc) {
@@ -418,8 +423,12 @@ int ltompc_destroy(ltompc_handle h) {
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->h_active) (void)hipHostFree(h->h_active);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-  if (h->plant_stream) (void)hipStreamDestroy(h->plant_stream);
-  if (h->roll_ev) (void)hipEventDestroy(h->roll_ev);
+  for (auto& ps : h->plant_streams)
+    if (ps) (void)hipStreamDestroy(ps);
+  for (int i = 0; i < ltompc_solver::ROLL_RING; i++) {
+    if (h->ev_fin[i]) (void)hipEventDestroy(h->ev_fin[i]);
+    if (h->ev_done[i]) (void)hipEventDestroy(h->ev_done[i]);
+  }
   delete h;
   return 0;
 }
@@ -619,10 +628,15 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
   if (h->eval8) return fail("ltompc_rollout: latency-mode handles (8-lanes-per-slot kernels) are not supported by the rollout");
   HIPCHECK(hipSetDevice(h->device));
   if (ensure_unpacked(h)) return -1;  // the rollout works in the caller's order (index-list compaction only)
-  if (!h->plant_stream) {
-    HIPCHECK(hipStreamCreateWithFlags(&h->plant_stream, hipStreamNonBlocking));
-    HIPCHECK(hipEventCreateWithFlags(&h->roll_ev, hipEventDisableTiming));
+  constexpr int RING = ltompc_solver::ROLL_RING, NPS = ltompc_solver::ROLL_PLANTS;
+  if (!h->plant_streams[0]) {
+    for (auto& ps : h->plant_streams) HIPCHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    for (int i = 0; i < RING; i++) {
+      HIPCHECK(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
+    }
   }
+  bool done_pending[RING] = {};
   const int B = h->B, N = h->N, Bp = h->Bp;
   const bool ell = h->K.bd.nel > 0;
   const int prof = h->profiling;
@@ -647,22 +661,36 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
   bool first = true;
   int rc = 0;
   for (;; it++) {
-    const int np = la.n_pad, slot = (int)(it % 8);
-    HIPCHECK(hipMemsetAsync(h->d_roll + slot, 0, sizeof(int), h->stream));
+    const int np = la.n_pad, slot = (int)(it % RING);
+    int* const d_cnt = h->d_roll + 2 * slot;
+    int* const d_list = h->d_plist + (size_t)slot * Bp;
+    if (done_pending[slot]) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));  // (the plant kernel that read this slot's list, RING passes ago)
+    HIPCHECK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_roll_mark, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, (const double*)x_dev, h->K.o.resto_sticky,
                        (first && h->cold_next) ? 1 : 0);  // (after set_initial_guess there is no solve before this one to take stock of)
     hipLaunchKernelGGL(k_roll_init, dim3((N * np + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, la, (first && h->cold_next) ? 1 : 0);
     la.force_eval = 0;
     if (launch_iteration(h, L, la, (int)(it % ring), n_launch, ls_width, ell, false) < 0) { rc = -1; break; }
     hipLaunchKernelGGL(k_roll_finish, dim3((np + 63) / 64), dim3(64), 0, h->stream, h->W, la, u_log_dev, status_log_dev, iters_log_dev, n_ticks,
-                       h->d_roll + slot);
-    // the plant steps of the instances that have just converged: second stream, after this iteration's k_roll_finish
-    HIPCHECK(hipEventRecord(h->roll_ev, h->stream));
-    HIPCHECK(hipStreamWaitEvent(h->plant_stream, h->roll_ev, 0));
-    hipLaunchKernelGGL(k_roll_plant, dim3((B + 63) / 64), dim3(64), 0, h->plant_stream, h->K, h->W, x_dev, h->K.o.t_step, n_sub);
+                       d_cnt, d_list);
+    // The plant steps of the instances that have just converged (the list k_roll_finish made: a plant step is ~1 ms of one
+    // lane's work, so the wavefronts are dense) on another stream, after this pass's k_roll_finish.  Measured and left at that:
+    // the solver kernels are 10 - 15 % slower at full width while plant wavefronts are resident, and k_riccati8 (exactly one
+    // wavefront per SIMD at 8192 instances) 0.29 -> 0.45 ms; holding the plant kernel back until the Riccati kernel has run and
+    // making the next one wait for it restores k_riccati8, but beside the big kernels a plant step takes 1.5 ms, longer than a
+    // pass, and the solver stream then waits 0.5 ms per pass (scratch/rtrace.sh).
+    {
+      hipStream_t ps = h->plant_streams[it % NPS];
+      HIPCHECK(hipEventRecord(h->ev_fin[slot], h->stream));
+      HIPCHECK(hipStreamWaitEvent(ps, h->ev_fin[slot], 0));
+      hipLaunchKernelGGL(k_roll_plant, dim3((n_launch + 63) / 64), dim3(64), 0, ps, h->K, h->W, x_dev, h->K.o.t_step, n_sub, (const int*)(d_cnt + 1),
+                         (const int*)d_list);
+      HIPCHECK(hipEventRecord(h->ev_done[slot], ps));
+      done_pending[slot] = true;
+    }
     first = false;
     if ((it + 1) % h->poll_every == 0) {
-      HIPCHECK(hipMemcpyAsync(h->h_active, h->d_roll + slot, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHECK(hipMemcpyAsync(h->h_active, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIPCHECK(hipStreamSynchronize(h->stream));
       const int n_left = h->h_active[0];  // instances that still have ticks to do (counted before this iteration's plant steps)
@@ -683,7 +711,7 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
       }
     }
   }
-  HIPCHECK(hipStreamSynchronize(h->plant_stream));
+  for (auto& ps : h->plant_streams) HIPCHECK(hipStreamSynchronize(ps));
   HIPCHECK(hipStreamSynchronize(h->stream));
   HIPCHECK(hipGetLastError());
   h->profiling = prof;

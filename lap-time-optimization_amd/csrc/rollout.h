@@ -7,9 +7,10 @@
 // a slow instance delays only itself.  Per instance the arithmetic is the synchronous loop's, tick by tick (an instance's
 // results do not depend on the batch it is solved in), so the controls are bit-identical to make_step + plant_step in a loop.
 //
-// Cycle of an instance (SI_PHASE): SOLVING -> (converged: k_roll_finish logs u0 / status, u_prev := u0) PLANT -> (k_roll_plant, on
-// a second stream: RK4 plant step, ticks left -= 1) READY or FINAL -> (k_roll_mark: new x0, status bookkeeping as k_load_x0)
-// INIT -> (k_roll_init: warm start of every slot as k_init) -> (k_roll_finish of that iteration) SOLVING.
+// Cycle of an instance (SI_PHASE): SOLVING -> (converged: k_roll_finish logs u0 / status, u_prev := u0, appends the instance to
+// the pass's plant list) PLANT -> (k_roll_plant over that list, on another stream: RK4 plant step, ticks left -= 1) READY or
+// FINAL -> (k_roll_mark: new x0, status bookkeeping as k_load_x0) INIT -> (k_roll_init: warm start of every slot as k_init)
+// -> (k_roll_finish of that iteration) SOLVING.
 // Each transition is made by ONE thread per instance in a kernel of its own, so that the thread-per-(interval, instance)
 // kernels see one state for all their threads; the solver kernels only look at SI_DONE, which stays 1 outside SOLVING.
 #pragma once
@@ -50,7 +51,7 @@ __global__ void k_roll_init(const Consts* __restrict__ Kp, const Work* __restric
 }
 // end of an iteration: INIT -> SOLVING; SOLVING and converged -> log, u_prev := u0, PLANT.  count: instances not FINAL.
 __global__ void k_roll_finish(Work W, Launch la, double* __restrict__ u_log, int* __restrict__ st_log, int* __restrict__ it_log, int n_ticks,
-                              int* __restrict__ count) {
+                              int* __restrict__ count, int* __restrict__ plant_list) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= la.nact[0]) return;
   const int b = la.act[j];
@@ -67,17 +68,17 @@ __global__ void k_roll_finish(Work W, Launch la, double* __restrict__ u_log, int
     if (u_log) u_log[((size_t)b * n_ticks + t) * 2] = a, u_log[((size_t)b * n_ticks + t) * 2 + 1] = c;
     if (st_log) st_log[(size_t)b * n_ticks + t] = STI(SI_STATUS);
     if (it_log) it_log[(size_t)b * n_ticks + t] = STI(SI_ITERS);
-    __threadfence();  // (u_prev before PLANT: the plant kernel runs on another stream)
     STI(SI_PHASE) = PH_PLANT;
+    plant_list[atomicAdd(count + 1, 1)] = b;  // (the plant kernel of this pass starts after this kernel has finished)
   }
 }
-// PLANT -> READY / FINAL: the plant step of the instances that have just converged (second stream, concurrent with the solver)
-__global__ void k_roll_plant(Consts K, Work W, double* x_rm, double dt, int n_sub) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= W.B) return;
+// PLANT -> READY / FINAL: the plant step of the instances that converged in one pass (its list; another stream, concurrent with
+// the solver)
+__global__ void k_roll_plant(Consts K, Work W, double* x_rm, double dt, int n_sub, const int* __restrict__ n_list, const int* __restrict__ list) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_list[0]) return;
+  const int b = list[j];
   volatile int* ph = &W.si[(size_t)SI_PHASE * W.Bp + b];
-  if (*ph != PH_PLANT) return;
-  __threadfence();
   double x[8], y[8], uu[2] = {W.uprev[b], W.uprev[(size_t)W.Bp + b]};
 #pragma unroll
   for (int i = 0; i < 8; i++) x[i] = x_rm[(size_t)b * 8 + i];
