@@ -68,11 +68,13 @@ struct ltompc_solver {
   int cur_iter = 0;   // interior-point iteration the launches being issued belong to
   int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum (k_status_counts)
   // rollout: per pass (ring slot) the number of instances that still have ticks to do and the list of the instances that
-  // converged in it; their plant steps run beside the solver, on a few streams in turn (a plant step takes ~3 narrow passes)
+  // converged in it; their plant steps run beside the solver, on two low-priority streams in turn (a plant kernel takes 1 - 2 ms,
+  // longer than a pass: one stream cannot keep up, 1870 ms instead of 1170 ms for 20 ticks; four are slower than two)
   static constexpr int ROLL_RING = 16, ROLL_PLANTS = 4;
   int* d_roll = nullptr;    // [ROLL_RING][2]: instances not FINAL, length of the plant list
   int* d_plist = nullptr;   // [ROLL_RING][Bp]
   hipStream_t plant_streams[ROLL_PLANTS] = {};
+  int n_plant_streams = 2;  // LTOMPC_PLANT_STREAMS (1 .. ROLL_PLANTS)
   hipEvent_t ev_fin[ROLL_RING] = {}, ev_done[ROLL_RING] = {};  // pass finished (solver stream) / its plant steps done (plant stream)
   long long roll_iterations = 0, roll_launches = 0;
   double ms_by_kernel[NKERN] = {};
@@ -342,6 +344,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     if (s1) h->step1_width = atoi(s1);
     const char* t = getenv("LTOMPC_RIC1");
     if (t) h->ric1_width = atoi(t);
+    const char* npl = getenv("LTOMPC_PLANT_STREAMS");
+    if (npl) h->n_plant_streams = std::min((int)ltompc_solver::ROLL_PLANTS, std::max(1, std::atoi(npl)));
     const char* sw = getenv("LTOMPC_SWEEPS_W");
     if (sw) h->sweeps_width = atoi(sw);
     // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
@@ -628,9 +632,14 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
   if (h->eval8) return fail("ltompc_rollout: latency-mode handles (8-lanes-per-slot kernels) are not supported by the rollout");
   HIPCHECK(hipSetDevice(h->device));
   if (ensure_unpacked(h)) return -1;  // the rollout works in the caller's order (index-list compaction only)
-  constexpr int RING = ltompc_solver::ROLL_RING, NPS = ltompc_solver::ROLL_PLANTS;
+  constexpr int RING = ltompc_solver::ROLL_RING;
   if (!h->plant_streams[0]) {
-    for (auto& ps : h->plant_streams) HIPCHECK(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
+    // low priority: the plant steps are not urgent, and the runtime keeps a pool of hardware queues per priority level, so
+    // a plant stream never shares its hardware queue with the solver stream (sharing one serialises the 2 ms plant kernels
+    // with the solver's: measured 1250 - 1870 ms instead of 1150 ms for 20 ticks, depending on what other streams the process has)
+    int prio_low = 0, prio_high = 0;
+    HIPCHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+    for (int i = 0; i < h->n_plant_streams; i++) HIPCHECK(hipStreamCreateWithPriority(&h->plant_streams[i], hipStreamNonBlocking, prio_low));
     for (int i = 0; i < RING; i++) {
       HIPCHECK(hipEventCreateWithFlags(&h->ev_fin[i], hipEventDisableTiming));
       HIPCHECK(hipEventCreateWithFlags(&h->ev_done[i], hipEventDisableTiming));
@@ -680,7 +689,7 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
     // making the next one wait for it restores k_riccati8, but beside the big kernels a plant step takes 1.5 ms, longer than a
     // pass, and the solver stream then waits 0.5 ms per pass (scratch/rtrace.sh).
     {
-      hipStream_t ps = h->plant_streams[it % NPS];
+      hipStream_t ps = h->plant_streams[it % h->n_plant_streams];
       HIPCHECK(hipEventRecord(h->ev_fin[slot], h->stream));
       HIPCHECK(hipStreamWaitEvent(ps, h->ev_fin[slot], 0));
       hipLaunchKernelGGL(k_roll_plant, dim3((n_launch + 63) / 64), dim3(64), 0, ps, h->K, h->W, x_dev, h->K.o.t_step, n_sub, (const int*)(d_cnt + 1),
@@ -711,7 +720,7 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
       }
     }
   }
-  for (auto& ps : h->plant_streams) HIPCHECK(hipStreamSynchronize(ps));
+  for (int i = 0; i < h->n_plant_streams; i++) HIPCHECK(hipStreamSynchronize(h->plant_streams[i]));
   HIPCHECK(hipStreamSynchronize(h->stream));
   HIPCHECK(hipGetLastError());
   h->profiling = prof;
