@@ -873,42 +873,44 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       // 2. element (i, g) of Hxx, row i of Hux^T, gx_i; the operands of the lane's element of Huu / gu (step 3) are
       //    fetched here as well, with the lane's own column offsets (c1, d1) - selecting them from B0 / B1 / X0 / X1
       //    costs two v_cndmask per double, 130 VALU instructions per stage
-      double Ai[8], PAg[8], PAi[8], B0[8], B1[8], X0[8], X1[8], Pbv[8], Bc[8], Xc[8], Xd[8], PBd[8];
-#pragma unroll
-      for (int l = 0; l < 8; l++) {
-        Ai[l] = qk[QP_A + l * 8 + i], PAg[l] = L.PA[l * 8 + g], PAi[l] = L.PA[l * 8 + i];
-        B0[l] = qk[QP_B + l * 2], B1[l] = qk[QP_B + l * 2 + 1], X0[l] = L.Pxv[l * 2], X1[l] = L.Pxv[l * 2 + 1];
-        Pbv[l] = L.Pb[l];
-        Bc[l] = qk[QP_B + l * 2 + c1], Xc[l] = L.Pxv[l * 2 + c1], Xd[l] = L.Pxv[l * 2 + d1], PBd[l] = L.PB[l * 2 + d1];
-      }
+      //    Two batches of four rows (l): all eight at once are 104 doubles in flight, and the stage's loop invariants move to
+      //    the accumulation registers and back (37 v_accvgpr_read per stage).
       double hxx = cur.q_elem, Hxu[2] = {cur.S[0], cur.S[1]}, gx = cur.q;
-#pragma unroll
-      for (int l = 0; l < 8; l++) {
-        double ali = Ai[l];
-        hxx += ali * PAg[l];
-        double pali = PAi[l];
-        Hxu[0] += B0[l] * pali + X0[l] * ali;
-        Hxu[1] += B1[l] * pali + X1[l] * ali;
-        gx += ali * Pbv[l];
-      }
       // 3. Huu, gu: one element per lane (g = 0..3: Huu[g>>1][g&1], g = 4, 5: gu[g-4]), gathered with wave shuffles.
       //    Both sums are formed by every lane (no divergent branches, no run-time indices into register arrays: those
       //    would live in scratch, and a scratch reload waits for the RC stores of the stage before); Bg = column d1 of B
-      double he;
-      {
-        const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);     // Rm[sidx(c, d)]
-        const double pvv = c1 ? (d1 ? Pvv[3] : Pvv[2]) : (d1 ? Pvv[1] : Pvv[0]);  // Pvv[c * 2 + d]
-        double s = rm + pvv;
+      const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);     // Rm[sidx(c, d)]
+      const double pvv = c1 ? (d1 ? Pvv[3] : Pvv[2]) : (d1 ? Pvv[1] : Pvv[0]);  // Pvv[c * 2 + d]
+      double s = rm + pvv;
+      double sg = (d1 ? rr[1] : rr[0]) + r2d * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);  // gu[c], c = g & 1
 #pragma unroll
-        for (int l = 0; l < 8; l++) s += Bc[l] * PBd[l] + Bc[l] * Xd[l] + Xc[l] * Bg[l];
-        double heH = s;
-        if (c1 == d1) heH += r2c + delta_w;
-        // gu[c], c = g & 1
-        double sg = (d1 ? rr[1] : rr[0]) + r2d * ((d1 ? uk[1] : uk[0]) - (d1 ? vk[1] : vk[0])) + (d1 ? pv[1] : pv[0]);
+      for (int h = 0; h < 2; h++) {
+        double Ai[4], PAg[4], PAi[4], B0[4], B1[4], X0[4], X1[4], Pbv[4], Bc[4], Xc[4], Xd[4], PBd[4];
 #pragma unroll
-        for (int l = 0; l < 8; l++) sg += Bg[l] * Pbv[l] + Xd[l] * bl[l];
-        he = g < 4 ? heH : (g < 6 ? sg : 0.0);
+        for (int q = 0; q < 4; q++) {
+          const int l = h * 4 + q;
+          Ai[q] = qk[QP_A + l * 8 + i], PAg[q] = L.PA[l * 8 + g], PAi[q] = L.PA[l * 8 + i];
+          B0[q] = qk[QP_B + l * 2], B1[q] = qk[QP_B + l * 2 + 1], X0[q] = L.Pxv[l * 2], X1[q] = L.Pxv[l * 2 + 1];
+          Pbv[q] = L.Pb[l];
+          Bc[q] = qk[QP_B + l * 2 + c1], Xc[q] = L.Pxv[l * 2 + c1], Xd[q] = L.Pxv[l * 2 + d1], PBd[q] = L.PB[l * 2 + d1];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          double ali = Ai[q];
+          hxx += ali * PAg[q];
+          double pali = PAi[q];
+          Hxu[0] += B0[q] * pali + X0[q] * ali;
+          Hxu[1] += B1[q] * pali + X1[q] * ali;
+          gx += ali * Pbv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) s += Bc[q] * PBd[q] + Bc[q] * Xd[q] + Xc[q] * Bg[h * 4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) sg += Bg[h * 4 + q] * Pbv[q] + Xd[q] * bl[h * 4 + q];
       }
+      double heH = s;
+      if (c1 == d1) heH += r2c + delta_w;
+      const double he = g < 4 ? heH : (g < 6 ? sg : 0.0);
       double Huu[4], gu[2];
 #pragma unroll
       for (int q = 0; q < 4; q++) Huu[q] = __shfl(he, q + 8 * i);
