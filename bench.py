@@ -332,7 +332,7 @@ def main():
 
     # ---- extras (rank 0, after the timed region)
     extras = {}
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # (single-GPU runs only: the other ranks would wait or leave)
         # batch = 1 latency (second handle, same stream)
         m1 = ltompc.BatchedMPC(tables, n_horizon=N, batch=1, options=opts, device=local_rank)
         m1.set_stream(stream.cuda_stream)
@@ -435,7 +435,7 @@ def main():
     # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on ALL host cores, on the states, warm starts and
     #      previous controls the GPU handle holds after the timed region (i.e. the tick the GPU would solve next)
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # (on rank 0 at N = 1 only)
         from oracle import oracle as orc
         ncores = os.cpu_count() or 1
         nthreads, share = host_cpu_share()
