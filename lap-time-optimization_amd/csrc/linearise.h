@@ -496,9 +496,13 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
   for (int i = 0; i < 8; i++) PG(W.QP, QP_qx0 + i, k + 1, QP_NF) = S.gxp0[i], PG(W.QP, QP_qx1 + i, k + 1, QP_NF) = S.gxp1[i];
   // ---- residual partials (IPOPT's E_mu ingredients) ----
   {
-    double l1[8], l2[8], rd = 0.0, rp = 0.0, sm = 0.0;
+    double l1[8], l2[8], l1n[8], l2n[8], rd = 0.0, rp = 0.0, sm = 0.0;
+    // (the next slot's multipliers in the same batch: read where they are used, each pair sat in a basic block of its own
+    //  behind the test below, eight serialised round trips; the last slot reads its own and does not use them)
+    const int kn = k + 1 < N ? k + 1 : k;
+    const bool nxt = k + 1 < N && !reinit;  // (re-initialised: the next slot's multipliers are zeros)
 #pragma unroll
-    for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N);
+    for (int i = 0; i < 8; i++) l1[i] = PL(W.L1, i, k, N), l2[i] = PL(W.L2, i, k, N), l1n[i] = PL(W.L1, i, kn, N), l2n[i] = PL(W.L2, i, kn, N);
 #pragma unroll
     for (int a = 0; a < 8; a++) {
       double rcx = S.dcd[a] + 4.5 * l2[a];
@@ -506,7 +510,11 @@ __device__ __forceinline__ void d_eval(const Consts& K, const Work& W, const int
 #pragma unroll
       for (int i = 0; i <= ge_(a); i++)  // column a of E1 / E2: rows of the groups up to a's
         if (a >= elo_(i) && a <= ehi_(i)) rcx += S.E1[i * 8 + a] * l1[i], rxp += S.E2[i * 8 + a] * l2[i];
-      if (k + 1 < N && !reinit) rxp += 2.0 * PL(W.L1, a, k + 1, N) - 2.0 * PL(W.L2, a, k + 1, N);  // (re-initialised: zeros)
+      {
+        const double t = 2.0 * l1n[a] - 2.0 * l2n[a];
+        const double r2 = rxp + t;
+        rxp = nxt ? r2 : rxp;
+      }
       rd = fmax(rd, fmax(fabs(rcx), fabs(rxp)));
       rp = fmax(rp, fmax(fabs(S.G1[a]), fabs(S.G2[a])));
       sm += fabs(l1[a]) + fabs(l2[a]);
