@@ -233,6 +233,7 @@ def main():
         tick()
     torch.cuda.synchronize(dev)
     tm_warm = mpc.timing() if (not args.no_profile and args.warmup > 0) else None
+    log_warm = mpc.launch_log(with_iterations=True) if tm_warm is not None else None  # every launch of that tick, by class and width
     dom = max(tm_warm["ms"], key=lambda k: tm_warm["ms"][k]) if tm_warm is not None else None
 
     # ---- timed region: exactly K ticks.  After every tick: the device-side histogram of the statuses (one tiny kernel
@@ -324,6 +325,18 @@ def main():
                                       "achieved": fw_bytes / (fw_ms * 1e-3) / 1e9, "frac": fw_bytes / (fw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if pmc:
                 roofline["full_width"]["traffic"] = pmc.get("traffic")
+        # every class at FULL width (all B instances in the launch), from the warm-up tick whose launches were all bracketed:
+        # what the thread-per-(interval, instance) kernels and the 8-instances-per-wavefront sweep reach when the chip is full
+        if log_warm is not None:
+            wk, ww, wms, _ = log_warm
+            fwc = {}
+            for ci, cname in enumerate(names):
+                s3 = (wk == ci) & (ww == B)
+                if s3.any() and BYTES_BY_KERNEL[cname] > 0:
+                    t_ms, by = float(wms[s3].mean()), B * N * BYTES_BY_KERNEL[cname]
+                    fwc[KERNEL_OF_CLASS[cname]] = {"launches": int(s3.sum()), "avg_launch_ms": round(t_ms, 4), "algorithmic_bytes_per_launch": by,
+                                                   "achieved": round(by / (t_ms * 1e-3) / 1e9, 1), "frac": round(by / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            roofline["full_width_by_class"] = fwc
         by_width = {}
         for w in sorted(set(int(v) for v in width[sel]), reverse=True)[:12]:
             s2 = sel & (width == w)
