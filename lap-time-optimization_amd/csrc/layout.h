@@ -60,6 +60,9 @@ enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_S
              SI_SKIP_EVAL, SI_LSMORE, SI_PREV, SI_RESTO, SI_REINIT, SI_NRESTO,
              SI_STICKY,   // option resto_sticky: solves for which the instance still starts in elastic mode (kept between make_steps)
              SI_STARTEL,  // this solve started in elastic mode
+             SI_SWEEPS,   // passes this solve has used: one per Riccati head, plus one per sweep repeated inside a launch - what a
+                          // launch of ONE sweep per pass would have needed, so that the iteration budget (options.max_iter counts
+                          // passes) cuts a solve at the same point whatever the launch widths were
              // closed-loop rollout (rollout.h): where the instance is in its tick cycle, ticks it still has to do, finished for good
              SI_PHASE, SI_TICKS, SI_FINAL,
              SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)

@@ -38,6 +38,7 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = emax;
   STI(SI_REINIT) = 0;
   int iters = STI(SI_ITERS);
+  int passes = STI(SI_SWEEPS);  // (see layout.h: this kernel repeats failed sweeps inside the launch, each one a pass)
   int term = -1;
   if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
   else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
@@ -47,8 +48,9 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
       STI(SI_NACC) = na;
       if (na >= o.acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE;
     } else STI(SI_NACC) = 0;
-    if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+    if (term < 0 && (iters >= o.max_iter || passes >= o.max_iter)) term = LTOMPC_STATUS_MAX_ITER;
   }
+  STI(SI_SWEEPS) = ++passes;
   if (STI(SI_RESTO) == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {  // see d_head8
     const double e_tol = term == LTOMPC_STATUS_SOLVED ? o.tol : o.acceptable_tol;
     if (emax <= e_tol) {
@@ -243,6 +245,11 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
       numerical = true;
       break;
     }
+    if (passes >= o.max_iter) {  // out of passes
+      STI(SI_STATUS) = LTOMPC_STATUS_MAX_ITER, STI(SI_DONE) = 1;
+      return;
+    }
+    STI(SI_SWEEPS) = ++passes;
   }
   if (numerical) {
     STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
@@ -299,6 +306,7 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
   // delta_w (its blocks stay in HBM, k_eval skips it) instead of looping here, so that a launch never takes longer
   // than one sweep however hard the worst instance of the batch is.
   retry = live && STI(SI_RETRY);
+  const int passes = STI(SI_SWEEPS);  // passes used so far (see layout.h); the budget is options.max_iter of them
   const double rho = STD(ST_RHO);
   double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, emax = 0.0;
   for (int k = i; k < N; k += 8) {
@@ -336,7 +344,7 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
       int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
       if (i == 0) STI(SI_NACC) = na;
       if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
-      if (term < 0 && iters >= o.max_iter) term = LTOMPC_STATUS_MAX_ITER;
+      if (term < 0 && (iters >= o.max_iter || passes >= o.max_iter)) term = LTOMPC_STATUS_MAX_ITER;
     }
     if (STI(SI_RESTO) == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {
       // The elastic problem of the restoration phase has converged.  All elastic variables at (numerically) zero: its
@@ -359,6 +367,11 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     }
     if (term >= 0) live = false;
   }
+  if (live && retry && passes >= o.max_iter) {  // out of passes while repeating a sweep
+    if (i == 0) STI(SI_STATUS) = LTOMPC_STATUS_MAX_ITER, STI(SI_DONE) = 1;
+    live = false;
+  }
+  if (live && i == 0) STI(SI_SWEEPS) = passes + 1;
   if (valid && i == 0 && STI(SI_REINIT)) STI(SI_REINIT) = 0;  // the evaluation before this head has re-initialised the slots
   if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
   if (to_hard) live = false;  // (counted as unfinished above)
@@ -647,7 +660,9 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
       if (++tries > 40 || delta_w > 1e20) numerical = true;
       if (i == 0) STI(SI_NREG) += 1;
     }
-    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    const int passes_used = failed ? STI(SI_SWEEPS) : 0;
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps && passes_used < o.max_iter;  // (a repeated sweep is a pass)
+    if (again && i == 0) STI(SI_SWEEPS) = passes_used + 1;
     if (failed && !again) {  // continue in the next launch (or give up)
       if (i == 0) {
         STI(SI_STEP) = 0;
@@ -990,7 +1005,9 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
       if (++tries > 40 || delta_w > 1e20) numerical = true;
       if (i == 0) STI(SI_NREG) += 1;
     }
-    const bool again = failed && !numerical && sweep + 1 < max_sweeps;
+    const int passes_used = failed ? STI(SI_SWEEPS) : 0;
+    const bool again = failed && !numerical && sweep + 1 < max_sweeps && passes_used < o.max_iter;  // (a repeated sweep is a pass)
+    if (again && i == 0) STI(SI_SWEEPS) = passes_used + 1;
     if (failed && !again) {  // continue in the next launch (or give up)
       if (i == 0) {
         STI(SI_STEP) = 0;

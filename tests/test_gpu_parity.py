@@ -255,7 +255,7 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     monkeypatch.setenv("LTOMPC_COMPACT", "0")
     u_nc, s_nc = run()
     assert np.array_equal(u_nc, u_ref) and np.array_equal(s_nc["status"], s_ref["status"])
-    solved = s_ref["status"] == 0   # (iteration counts of unsolved instances depend on how many launches they were given)
+    solved = s_ref["status"] == 0
     assert np.array_equal(s_nc["iters"][solved], s_ref["iters"][solved])
     monkeypatch.setenv("LTOMPC_COMPACT", "1")
     monkeypatch.setenv("LTOMPC_PACK", "0")   # re-packing of the index list only vs moving the instances' data: same bits
@@ -280,6 +280,38 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     u_se, s_se = run()
     ok = (s_se["status"] == 0) & (s_ref["status"] == 0)
     assert ok.mean() >= 0.98 and np.abs(u_se - u_ref)[ok].max() < 1e-6
+
+
+def test_iteration_budget_cuts_a_solve_at_the_same_point_on_every_kernel_path(pkg, tables, gpu_lib, monkeypatch):
+    """options.max_iter counts passes (Riccati heads; a sweep repeated inside a narrow launch counts as one more, SI_SWEEPS), so a
+    solve that runs out of them stops at the same iterate whether its last sweeps ran one per launch or several per launch: also
+    the instances that end with status MAX_ITER, and the warm ticks that start from them, are bit-identical across the kernel
+    paths.  (Before: a launch of at most 16 instances held up to four sweeps but counted as one pass, and such a solve went on for
+    longer than with one sweep per launch.)"""
+    B, N = 520, 40
+    x0 = pkg.sample_x0(tables, B, seed=12345)
+    def run():
+        o = pkg.default_options(); o.max_iter, o.latency_mode = 120, 2
+        m = pkg.BatchedMPC(tables, N, B, options=o)
+        m.set_initial_guess(x0)
+        x, out = x0.copy(), []
+        for _ in range(2):
+            u = m.make_step(x); st = m.stats()
+            out.append((u.copy(), st["status"].copy(), st["iters"].copy()))
+            x = m.plant_step(x, u, 100)
+        m.close()
+        return out
+    ref = run()
+    assert (ref[0][1] == 2).sum() >= 1, "the scenario is meant to contain solves that run out of passes"
+    for env in ({"LTOMPC_SWEEPS_W": "0"}, {"LTOMPC_RIC1": "0"}, {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}, {"LTOMPC_COMPACT": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        got = run()
+        for k in env:
+            monkeypatch.delenv(k)
+        for t in range(2):
+            assert np.array_equal(got[t][0], ref[t][0]), (env, t)
+            assert np.array_equal(got[t][1], ref[t][1]) and np.array_equal(got[t][2], ref[t][2]), (env, t)
 
 
 def _midtrack_x0(tables, s):
