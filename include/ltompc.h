@@ -111,7 +111,7 @@ typedef struct ltompc_options {
    * with some e > tol the problem is locally infeasible (status INFEASIBLE).  0 = no restoration: a failed line
    * search ends the solve with status STALLED after max_ls_fail attempts, as in round 1. */
   double resto_rho;       /* 1000 */
-  int max_iter;           /* controller.py:18 says 1000 */
+  int max_iter;           /* controller.py:18 says 1000.  Per instance: iterations plus repeated Riccati sweeps (inertia correction) */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
   int stall_iter;         /* stop (status STALLED) after this many consecutive steps with alpha <= 1e-3; 0 = off */
