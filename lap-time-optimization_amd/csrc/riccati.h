@@ -39,6 +39,10 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   STI(SI_REINIT) = 0;
   int iters = STI(SI_ITERS);
   int passes = STI(SI_SWEEPS);  // (see layout.h: this kernel repeats failed sweeps inside the launch, each one a pass)
+  if (passes > o.max_iter) {
+    STI(SI_STATUS) = LTOMPC_STATUS_MAX_ITER, STI(SI_DONE) = 1;
+    return;
+  }
   int term = -1;
   if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
   else if (E0 <= o.tol) term = LTOMPC_STATUS_SOLVED;
@@ -307,6 +311,14 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
   // than one sweep however hard the worst instance of the batch is.
   retry = live && STI(SI_RETRY);
   const int passes = STI(SI_SWEEPS);  // passes used so far (see layout.h); the budget is options.max_iter of them
+  if (live && passes > o.max_iter) {
+    // (a head that one sweep per launch would never have run: the host loop issues max_iter + 1 of them; reached when sweeps were
+    //  repeated inside launches and the pass before was the last one - e.g. the return from the restoration phase, which is
+    //  followed by a head of its own)
+    if (i == 0) STI(SI_STATUS) = LTOMPC_STATUS_MAX_ITER, STI(SI_DONE) = 1;
+    live = false, retry = false;
+  }
+  if (!__any(live)) return false;
   const double rho = STD(ST_RHO);
   double rd = 0.0, rp = 0.0, cmax = 0.0, cmin = 1e300, emax = 0.0;
   for (int k = i; k < N; k += 8) {

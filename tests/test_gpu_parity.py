@@ -288,10 +288,10 @@ def test_iteration_budget_cuts_a_solve_at_the_same_point_on_every_kernel_path(pk
     the instances that end with status MAX_ITER, and the warm ticks that start from them, are bit-identical across the kernel
     paths.  (Before: a launch of at most 16 instances held up to four sweeps but counted as one pass, and such a solve went on for
     longer than with one sweep per launch.)"""
-    B, N = 520, 40
-    x0 = pkg.sample_x0(tables, B, seed=12345)
+    B, N = 600, 40
+    x0 = pkg.sample_x0(tables, B, seed=4282)   # (contains an instance that returns from the restoration phase in its very last pass)
     def run():
-        o = pkg.default_options(); o.max_iter, o.latency_mode = 120, 2
+        o = pkg.default_options(); o.max_iter, o.latency_mode = 90, 2
         m = pkg.BatchedMPC(tables, N, B, options=o)
         m.set_initial_guess(x0)
         x, out = x0.copy(), []
@@ -303,7 +303,7 @@ def test_iteration_budget_cuts_a_solve_at_the_same_point_on_every_kernel_path(pk
         return out
     ref = run()
     assert (ref[0][1] == 2).sum() >= 1, "the scenario is meant to contain solves that run out of passes"
-    for env in ({"LTOMPC_SWEEPS_W": "0"}, {"LTOMPC_RIC1": "0"}, {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}, {"LTOMPC_COMPACT": "0"}):
+    for env in ({"LTOMPC_SWEEPS_W": "0"}, {"LTOMPC_SWEEPS_W": "512"}, {"LTOMPC_RIC1": "0"}, {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}, {"LTOMPC_COMPACT": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
