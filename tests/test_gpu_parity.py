@@ -314,6 +314,48 @@ def test_iteration_budget_cuts_a_solve_at_the_same_point_on_every_kernel_path(pk
             assert np.array_equal(got[t][1], ref[t][1]) and np.array_equal(got[t][2], ref[t][2]), (env, t)
 
 
+def test_extreme_states_get_a_status_and_do_not_disturb_their_neighbours(pkg, tables, gpu_lib):
+    """Instances with absurd measured states inside a normal batch (a standing car, 120 m/s, 40 m off the track, states outside
+    their bounds, arc lengths off the tables, the centre of curvature): every one of them ends with a status and finite controls
+    within the iteration budget, and the other instances - some of them share wavefronts with them in the 8-instances-per-wavefront
+    sweep - get bit for bit the result they get without them (cold tick and the warm tick after it)."""
+    N, B = 20, 256
+    x0 = pkg.sample_x0(tables, B, seed=5)
+    o = pkg.default_options(); o.latency_mode, o.max_iter = 2, 150
+    def run(x):
+        m = pkg.BatchedMPC(tables, N, B, options=o)
+        m.set_initial_guess(x)
+        out, xx = [], x.copy()
+        for _ in range(2):
+            u = m.make_step(xx); st = m.stats()
+            out.append((u.copy(), st["status"].copy(), st["iters"].copy()))
+            xx = m.plant_step(xx, u, 50)
+        m.close()
+        return out
+    ref = run(x0)
+    x = x0.copy()
+    pos = [3, 11, 20, 37, 64, 65, 100, 127, 128, 129, 200, 201, 250, 255]
+    x[3, 3] = 0.0
+    x[11, 3:6] = 0.0
+    x[20, 3] = 1e-9
+    x[37, 3] = 120.0
+    x[64, 1], x[65, 1] = 40.0, -40.0
+    x[100, 2], x[127, 2] = np.pi / 2, -3.0
+    x[128, 0], x[129, 0] = -50.0, 5000.0
+    x[200, 6], x[200, 7] = 1.5, 5.0
+    x[201, 5] = 50.0
+    x[250, 4] = -30.0
+    kap = np.interp(x[255, 0], tables.s_kappa, tables.kappa)
+    x[255, 1] = 1.0 / kap if abs(kap) > 1e-6 else 1e6
+    got = run(x)
+    others = np.ones(B, bool); others[pos] = False
+    for t in range(2):
+        assert np.array_equal(got[t][0][others], ref[t][0][others]) and np.array_equal(got[t][1][others], ref[t][1][others])
+        assert np.array_equal(got[t][2][others], ref[t][2][others])
+        assert np.isfinite(got[t][0]).all() and ((got[t][1] >= 0) & (got[t][1] <= 5)).all()
+        assert (got[t][2][pos] <= o.max_iter).all()
+
+
 def _midtrack_x0(tables, s):
     """Noise-free state on the centre of the drivable band at arc length s."""
     nl, nr = np.interp(s, tables.s_arc, tables.n_left), np.interp(s, tables.s_arc, tables.n_right)
