@@ -45,3 +45,11 @@ for t in range(2):
           f"status {np.array_equal(got[t][1][others], ref[t][1][others])}, iters {np.array_equal(got[t][2][others], ref[t][2][others])}")
 for name, j in idx.items():
     print(f"  {name:46s}: status {ltompc.STATUS_NAMES[got[0][1][j]] if hasattr(ltompc, 'STATUS_NAMES') else got[0][1][j]} after {got[0][2][j]} iterations, u0 {got[0][0][j]}, finite {np.isfinite(got[0][0][j]).all()} | next tick: status {got[1][1][j]}, u0 finite {np.isfinite(got[1][0][j]).all()}")
+# the oracle on the same extreme states (cold tick)
+from oracle import oracle as orc
+oo = orc.default_options(); oo.max_iter = 150
+O = orc.Oracle(T.packed(), options=oo)
+r = O.solve(x[pos], N, nthreads=8)
+print("GPU vs oracle on the extreme states (status, iterations):")
+for (name, j), q in zip(idx.items(), range(len(pos))):
+    print(f"  {name:46s}: gpu ({got[0][1][j]}, {got[0][2][j]})  oracle ({r['status'][q]}, {r['iters'][q]})  |du0| {np.abs(got[0][0][j] - r['u0'][q]).max():.2e}")

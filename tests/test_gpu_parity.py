@@ -464,8 +464,9 @@ def test_latency_mode_kernels_agree(pkg, tables, oracle, gpu_lib):
         return out
     a, b = run(2, 1), run(1, 1)
     for key in ("qp", "dc", "nl2"):
-        scale = np.maximum(np.maximum(np.abs(a[key]), np.abs(b[key])), 1e-3)
-        assert (np.abs(a[key] - b[key]) / scale).max() < 1e-10, key
+        w = np.isfinite(a[key]) | np.isfinite(b[key])   # (the padding slots of the buffers are never written: NaN under LTOMPC_POISON=1)
+        scale = np.maximum(np.maximum(np.abs(a[key][w]), np.abs(b[key][w])), 1e-3)
+        assert w.sum() > 0.3 * w.size and (np.abs(a[key][w] - b[key][w]) / scale).max() < 1e-10, key
     a, b, auto = run(2, 300), run(1, 300), run(0, 300)
     assert np.array_equal(auto["u0"], b["u0"])  # 24 instances: auto = latency mode
     ok = (a["status"] == 0) & (b["status"] == 0)
