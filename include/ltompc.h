@@ -38,10 +38,13 @@ extern "C" {
 #define LTOMPC_STATUS_NUMERICAL 3       /* non-finite value / regularisation overflow             */
 #define LTOMPC_STATUS_STALLED 4         /* no progress and the restoration phase could not help (or is
                                            switched off): IPOPT's 'restoration failed'              */
-#define LTOMPC_STATUS_INFEASIBLE 5      /* the restoration phase converged to a stationary point of the
-                                           constraint violation with violation > 0: the horizon problem is
-                                           locally infeasible (IPOPT: 'converged to a point of local
-                                           infeasibility'); the least-violation iterate is returned    */
+#define LTOMPC_STATUS_INFEASIBLE 5      /* the restoration phase converged, at its largest penalty
+                                           (options.resto_rho_max), to a point where a track constraint stays
+                                           violated by more than tol: a stationary point of the constraint
+                                           violation up to 1 / resto_rho_max (IPOPT: 'converged to a point of
+                                           local infeasibility'); that least-violation iterate is returned.
+                                           Also: the measured state x0 itself violates a track constraint
+                                           (options.node0_check: the reference's NLP has no feasible point) */
 
 /* Vehicle + objective + bounds.  Defaults (ltompc_default_params) are the values the reference
  * actually uses, including its quirks: D_f = D_r = 1.0 because model.py:42-64
@@ -111,6 +114,17 @@ typedef struct ltompc_options {
    * with some e > tol the problem is locally infeasible (status INFEASIBLE).  0 = no restoration: a failed line
    * search ends the solve with status STALLED after max_ls_fail attempts, as in round 1. */
   double resto_rho;       /* 1000 */
+  /* Penalty escalation of the restoration phase.  An elastic problem that has converged with an elastic variable > tol has
+   * only shown that, at its penalty, violating is cheaper than complying (the multiplier of that constraint sits at the
+   * penalty); a feasible NLP whose multipliers exceed resto_rho ends there too.  So the penalty of THAT instance is
+   * multiplied by resto_rho_factor (elastic variables, slacks, barrier re-centred at the current primal point, as at the
+   * entry of the phase) and the elastic problem is solved again, until all elastic variables are <= tol (back to the hard
+   * constraints, status SOLVED) or the penalty has reached resto_rho_max: only then the status is INFEASIBLE, a stationary
+   * point of  objective / resto_rho_max + violation,  i.e. of the constraint violation itself up to 1 / resto_rho_max (IPOPT's
+   * restoration phase minimises the violation alone).  resto_rho_factor <= 1 or resto_rho_max <= resto_rho: no escalation,
+   * INFEASIBLE means "at penalty resto_rho" (round 2's behaviour). */
+  double resto_rho_max;    /* 1e7 */
+  double resto_rho_factor; /* 1e4 (one step to resto_rho_max) */
   int max_iter;           /* controller.py:18 says 1000.  Per instance: iterations plus repeated Riccati sweeps (inertia correction) */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
@@ -140,6 +154,23 @@ typedef struct ltompc_options {
                              happening.  A solve that starts in elastic mode ends like any restoration: back on the hard
                              constraints when every elastic variable is <= tol (status SOLVED), INFEASIBLE otherwise.
                              0: every solve starts on the hard constraints (IPOPT).                              (0) */
+  int node0_check;        /* do_mpc registers the track constraints at the nodes 0 .. N-1 (controller.py:69-70); node 0 is the measured
+                             state, so its two rows are constants: they cannot change the minimiser, but when x0 violates them
+                             the reference's NLP has no feasible point whatever the solver does.  1: the solve runs as always
+                             (the rows of node 0 left out), and a measured state with g(x0) > acceptable_tol turns a converged
+                             status into INFEASIBLE (violation = g(x0)), one with tol < g(x0) <= acceptable_tol turns SOLVED into
+                             ACCEPTABLE (IPOPT's error then cannot fall below g(x0)).  0: node 0 ignored (round 2).       (1) */
+  int warm_fallback_iter; /* safeguard of options.mu_init_warm: a warm-started solve that began at mu_init_warm and has gone this
+                             many iterations without a decrease of the barrier parameter (it is cycling: the small barrier
+                             keeps it at a point that is not central) starts again from its current primal point with the
+                             equality multipliers at 0 and the barrier at mu_init, once per solve.  0 = off.          (25) */
+  int resto_shift_retry;  /* 1: before the restoration phase proper, a WARM-started solve whose line search has failed (or
+                             stalled) starts once more on the hard constraints from its own starting point moved one interval
+                             ahead (options.warm_shift's rule), multipliers 0, barrier at mu_init.  do_mpc re-uses the previous
+                             solution un-shifted, one interval behind the new measured state, and that mismatch is what jams
+                             many of these solves: from the shifted point they converge in ~15 iterations where the elastic
+                             problem started at the jam point drifts into a local minimum of the violation.
+                             0: straight to the restoration phase (round 2).  Ignored with warm_shift = 1.            (1) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),
@@ -235,6 +266,13 @@ int ltompc_get_counters(ltompc_handle h, int* n_reg, int* n_lsfail);
  * largest elastic variable at termination, i.e. the remaining violation of the track constraints in metres (> tol for
  * status INFEASIBLE; 0 for instances that ended on the hard constraints). */
 int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation);
+
+/* Recovery steps of the last solve (host, out; any may be NULL): n_shift - the solve started again from its shifted starting
+ * point (options.resto_shift_retry; 0 or 1); n_fallback - a tuned warm start fell back to mu_init (options.warm_fallback_iter);
+ * g0 - the largest track constraint at the measured state x0 (options.node0_check; > 0: x0 is outside the band);
+ * solver_status - the solver's own termination status, before the node-0 rule; penalty - the elastic variables' penalty at
+ * termination (0: hard constraints; resto_rho_max for status INFEASIBLE after an escalated restoration). */
+int ltompc_get_recovery(ltompc_handle h, int* n_shift, int* n_fallback, double* g0, int* solver_status, double* penalty);
 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:

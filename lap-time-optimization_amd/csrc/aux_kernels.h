@@ -43,9 +43,17 @@ __device__ __forceinline__ void d_init_slot(const Consts& K, const Work& W, cons
 #pragma unroll
   for (int i = 0; i < 8; i++) xp[i] = cold ? x0[i] : PL(W.X, i, k + 1, N + 1), c[i] = cold ? x0[i] : PL(W.C, i, k, N);
   u[0] = cold ? 0.0 : PL(W.U, 0, k, N), u[1] = cold ? 0.0 : PL(W.U, 1, k, N);
-  const double mu = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
-  const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu) : 0.0;
+  if (!cold && K.o.resto_shift_retry && !K.o.warm_shift) {
+    // the solve's own starting point, for options.resto_shift_retry (d_pick / d_update); indexed by the caller's instance index
+    const size_t ob = W.orig[b];
+#pragma unroll
+    for (int i = 0; i < 8; i++) W.BK[((size_t)i * N + k) * W.Bp + ob] = xp[i], W.BK[((size_t)(8 + i) * N + k) * W.Bp + ob] = c[i];
+    W.BK[((size_t)16 * N + k) * W.Bp + ob] = u[0], W.BK[((size_t)17 * N + k) * W.Bp + ob] = u[1];
+  }
+  const double mu_s = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
+  const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu_s) : 0.0;
   const double rho = start_elastic ? K.o.resto_rho : K.o.soft_rho;  // (the restoration phase replaces it per instance, see d_pick)
+  const double mu = mu_s * pen_scale(rho);  // (penalty scale, layout.h: 1 unless rho > RHO_UNIT)
   init_slot_slacks<BoundsAny>(K, W, k, b, mu, eps, rho, xp, c, u);
   if (k == 0) {
     double* st = W.st;
@@ -60,6 +68,14 @@ __device__ __forceinline__ void d_init_slot(const Consts& K, const Work& W, cons
     for (int i = 0; i < SI_NF; i++)
       if (i != SI_PREV && (i != SI_STICKY || cold) && i != SI_PHASE && i != SI_TICKS && i != SI_FINAL) W.si[(size_t)i * W.Bp + b] = 0;
     W.si[(size_t)SI_STATUS * W.Bp + b] = LTOMPC_STATUS_MAX_ITER;
+    W.si[(size_t)SI_WARM * W.Bp + b] = cold ? 0 : 1;
+    W.si[(size_t)SI_FBARMED * W.Bp + b] = (!cold && !after_failure && K.o.mu_init_warm > 0 && K.o.warm_fallback_iter > 0) ? 1 : 0;
+    {  // options.node0_check: the track constraints at the measured state (node 0 of do_mpc's NLP), at the final smoothing
+      const double eps0 = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? K.o.smooth_eps_min : 0.0;
+      double g0[3];
+      cons_eval(K.p, K.T, eps0, x0, g0, nullptr, nullptr, nullptr, nullptr, nullptr);
+      st[(size_t)ST_G0 * W.Bp + b] = fmax(g0[0], fmax(g0[1], g0[2]));
+    }
     if (start_elastic) W.si[(size_t)SI_RESTO * W.Bp + b] = 1, W.si[(size_t)SI_NRESTO * W.Bp + b] = 1, W.si[(size_t)SI_STARTEL * W.Bp + b] = 1;
   }
 }
@@ -214,7 +230,9 @@ __global__ void k_pack(Work W, const int* __restrict__ perm, const int* __restri
 __device__ __forceinline__ void d_load_x0(const Work& W, const double* __restrict__ x0_rm, const int b, const size_t r, const int sticky, const int update) {
 #pragma unroll
   for (int i = 0; i < 8; i++) W.x0[(size_t)i * W.Bp + b] = x0_rm[r * 8 + i];
-  const int prev = W.si[(size_t)SI_STATUS * W.Bp + b];
+  // (the solver's own status: the node-0 rule of options.node0_check may have turned a converged solve into INFEASIBLE)
+  const int node0 = W.si[(size_t)SI_NODE0 * W.Bp + b];
+  const int prev = node0 ? node0 - 1 : W.si[(size_t)SI_STATUS * W.Bp + b];
   W.si[(size_t)SI_PREV * W.Bp + b] = prev;  // k_init resets the rest
   if (update && sticky > 0) {
     // jammed on the hard constraints (restoration entered from them) or infeasible: the next `sticky` solves start elastic

@@ -13,6 +13,13 @@ constexpr int FILTER_MAX = 16;
 constexpr double DW_KEEP = 1e-5;  // regularisation below this is dropped to exactly 0
 constexpr int MAX_LS = 12;
 constexpr double ELASTIC_CP_VIOL = 0.1;  // [m] violation of a track constraint above which its elastic variable starts on the central path
+// Penalty scale S of an instance (include/ltompc.h, resto_rho_max): with elastic variables that cost rho > RHO_UNIT the solve runs
+// in the units of  objective / S + RHO_UNIT * violation,  S = rho / RHO_UNIT - tolerances, barrier parameter, regularisation and the
+// objective side of the filter are S times their options (at rho = 1e7 the unscaled tolerance 1e-8 on gradients of size 1e7 is
+// below the rounding floor; scaled, the solver sees the problem it handles at rho = 1000).  S = 1 otherwise, and x * 1.0 is exact:
+// nothing changes for the other instances.
+constexpr double RHO_UNIT = 1000.0;
+__host__ __device__ __forceinline__ double pen_scale(const double rho) { return rho > RHO_UNIT ? rho / RHO_UNIT : 1.0; }
 
 // fields of the stage-QP buffer written by k_eval and read by k_riccati
 enum : int {
@@ -46,7 +53,8 @@ enum : int {
   ST_C00,  // lterm(x_0) for the current ST_EPS: a constant of the solve between two changes of the table smoothing
   ST_RHO,  // penalty of the elastic variables of the track constraints: options.soft_rho, or options.resto_rho while
            // the instance is in its restoration phase (0: hard constraints)
-  ST_VIOL, // largest elastic variable seen by the last termination test
+  ST_VIOL, // largest elastic variable seen by the last termination test (g(x0) when the node-0 rule decided the status)
+  ST_G0,   // largest track constraint at the measured state x0 (options.node0_check), k_init
   ST_NF
 };
 // per-instance int state
@@ -65,6 +73,15 @@ enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_S
                           // passes) cuts a solve at the same point whatever the launch widths were
              // closed-loop rollout (rollout.h): where the instance is in its tick cycle, ticks it still has to do, finished for good
              SI_PHASE, SI_TICKS, SI_FINAL,
+             SI_WARM,     // this solve is warm-started (k_init)
+             SI_SHIFT,    // options.resto_shift_retry: d_pick has sent the solve back to its own starting point moved one interval ahead;
+                          // d_update (the next slot-parallel kernel) loads it from the backup planes, the next head clears the flag
+             SI_NSHIFT,   // times that happened in this solve (0 or 1)
+             SI_SINCEMU,  // options.warm_fallback_iter: iterations since the barrier parameter last decreased
+             SI_FBARMED,  // ... the fallback is still available to this solve (it started at mu_init_warm)
+             SI_NFALLBACK,
+             SI_NODE0,    // options.node0_check turned the solver's status (value - 1: SOLVED / ACCEPTABLE) into INFEASIBLE: the next
+                          // solve is warm-started as after a converged one
              SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)
 
 struct Work {
@@ -82,6 +99,10 @@ struct Work {
   gptr<int> active;    // [max_iter+2] number of unfinished instances after iteration i
   gptr<double> DBG;  // [8][N][Bp] scratch planes for debugging
   gptr<int> ls_list, ls_count;  // instances whose full step was rejected in this iteration (phase 1 of the line search)
+  // options.resto_shift_retry: the primal starting point of the current solve, [18][N][Bp]: x_{k+1} (8), c_k (8), u_k (2) of slot k,
+  // indexed by the CALLER's instance index orig[b] (re-packing moves instances between slots, not this array)
+  gptr<double> BK;
+  gptr<const int> orig;  // slot -> caller's index (identity while the instances are not packed)
 };
 
 // What changes from launch to launch (kernel argument; Work and Consts are read from device memory).  Compaction of the

@@ -198,6 +198,7 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
     nfilt = 0;
   }
   const double g_th = 1e-5, g_ph = 1e-8, eta_ph = 1e-8, s_th = 1.1, s_ph = 2.3, dlt = 1.0;
+  const double S = pen_scale(STD(ST_RHO)), iS = 1.0 / S;  // penalty scale (layout.h): the objective side of the tests in its units
   bool accepted = false;
   double alpha = a_pri;
   const int n_ls = o.n_linesearch;
@@ -212,11 +213,11 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
 #pragma unroll
     for (int f = 0; f < FILTER_MAX; f++) in_filter = in_filter || (f < nfilt && th >= fth[f] && ph >= fph[f]);
     if (in_filter) return false;
-    bool sw = (gphid < 0.0) && (alpha * pow(-gphid, s_ph) > dlt * pow(th0, s_th));
+    bool sw = (gphid < 0.0) && (alpha * pow(-gphid * iS, s_ph) > dlt * pow(th0, s_th));
     bool armijo = ph <= ph0 + eta_ph * alpha * gphid;
     bool ok;
     if (th0 <= theta_min && sw) ok = armijo;
-    else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * th0);
+    else ok = (th <= (1.0 - g_th) * th0) || (ph <= ph0 - g_ph * S * th0);
     if (!ok) return false;
     if (!(sw && armijo)) {  // augment the filter (written by lane i == 0, nobody reads it again in this launch)
       if (nfilt == FILTER_MAX) {
@@ -229,7 +230,7 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
       }
       if (i == 0) {
         W.filt[(size_t)(2 * nfilt) * W.Bp + b] = (1.0 - g_th) * th0;
-        W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * th0;
+        W.filt[(size_t)(2 * nfilt + 1) * W.Bp + b] = ph0 - g_ph * S * th0;
       }
       nfilt++;
     }
@@ -272,8 +273,8 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
       enter_resto = true, take = false;
     } else if (o.max_ls_fail > 0 && nf >= o.max_ls_fail) {
       give_up = true, take = false;
-    } else if (fr < 1e4) {
-      STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 : fr * 100.0;
+    } else if (fr < 1e4 * S) {
+      STD(ST_FORCE_REG) = fr == 0.0 ? 1e-2 * S : fr * 100.0;
       take = false;
     } else {
       nfilt = 0;
@@ -292,15 +293,24 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
     }
   }
   if (enter_resto) {
+    // First remedy (options.resto_shift_retry), once per warm-started solve: the jam may be the un-shifted warm start's doing
+    // (do_mpc re-uses the previous solution as it is, one interval behind the new measured state).  The solve starts again on the
+    // hard constraints from its own starting point moved one interval ahead (options.warm_shift's rule): d_update, the next
+    // slot-parallel kernel, loads the shifted point from the backup planes (SI_SHIFT), the next evaluation re-initialises
+    // slacks and multipliers (SI_REINIT).  The restoration phase proper follows if that start jams too:
     // the track constraints get elastic variables that cost resto_rho each; equality multipliers, slacks and the barrier
-    // parameter start again at the current primal point (the next evaluation kernel re-initialises its slots: SI_REINIT)
-    const double mu0 = o.mu_init;
-    STI(SI_RESTO) = 1, STI(SI_REINIT) = 1, STI(SI_NRESTO) += 1;
-    STD(ST_RHO) = o.resto_rho, STD(ST_MU) = mu0;
-    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu0) : 0.0;
+    // parameter start again at the current primal point.
+    const bool shift = o.resto_shift_retry && !o.warm_shift && STI(SI_WARM) && STI(SI_NSHIFT) == 0;
+    double rho_new = 0.0;
+    if (shift) STI(SI_SHIFT) = 1, STI(SI_NSHIFT) = 1;
+    else STI(SI_RESTO) = 1, STI(SI_NRESTO) += 1, rho_new = o.resto_rho;
+    const double mu0 = o.mu_init * pen_scale(rho_new);
+    STI(SI_REINIT) = 1;
+    STD(ST_RHO) = rho_new, STD(ST_MU) = mu0;
+    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * o.mu_init) : 0.0;
     if (STD(ST_EPS_NEXT) == STD(ST_EPS)) nfilt = 0, STD(ST_THETA0) = -1.0;  // (else: reset with the switch of the smoothing below)
     STD(ST_DW_LAST) = 0.0, STD(ST_FORCE_REG) = 0.0;
-    STI(SI_NTINY) = 0, STI(SI_NACC) = 0;
+    STI(SI_NTINY) = 0, STI(SI_NACC) = 0, STI(SI_SINCEMU) = 0;
   }
   STD(ST_ALPHA) = take ? alpha : 0.0, STD(ST_ADUA) = a_dua;
   STI(SI_STEP) = take ? 1 : 0;
@@ -335,6 +345,19 @@ __global__ void __launch_bounds__(64) k_pick(const Consts* __restrict__ Kp, cons
 // ------------------------------------------------------------------------------------------ k_update
 __device__ __forceinline__ void d_update(const Consts& K, const Work& W, const int k, const int b) {
   const int N = W.N;
+  if (W.si[(size_t)SI_SHIFT * W.Bp + b] && !W.si[(size_t)SI_DONE * W.Bp + b]) {
+    // options.resto_shift_retry (d_pick): slot k takes the primal point the solve started from, one interval ahead (the last
+    // interval repeated): x_{k+1}, c_k, u_k of the backup's slot min(k + 1, N - 1).  Slot-local writes, read-only source.
+    const size_t ob = W.orig[b];
+    const int ks = k + 1 <= N - 1 ? k + 1 : N - 1;
+    double v[18];
+#pragma unroll
+    for (int f = 0; f < 18; f++) v[f] = W.BK[((size_t)f * N + ks) * W.Bp + ob];
+#pragma unroll
+    for (int i = 0; i < 8; i++) PL(W.X, i, k + 1, N + 1) = v[i], PL(W.C, i, k, N) = v[8 + i];
+    PL(W.U, 0, k, N) = v[16], PL(W.U, 1, k, N) = v[17];
+    return;
+  }
   if (!W.si[(size_t)SI_STEP * W.Bp + b] || W.si[(size_t)SI_DONE * W.Bp + b]) return;
   const double alpha = W.st[(size_t)ST_ALPHA * W.Bp + b], a_dua = W.st[(size_t)ST_ADUA * W.Bp + b];
   const double mu = W.st[(size_t)ST_MU * W.Bp + b];

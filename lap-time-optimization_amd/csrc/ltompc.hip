@@ -242,7 +242,7 @@ int ensure_unpacked(ltompc_solver* h) {
 extern "C" {
 
 const char* ltompc_last_error(void) { return g_err.c_str(); }
-const char* ltompc_version(void) { return "ltompc 0.5 (gfx950, fp64; interior point with elastic-mode restoration, block-structured interval evaluation, LDS-staged wave-cooperative Riccati, data re-packing)"; }
+const char* ltompc_version(void) { return "ltompc 0.6 (gfx950, fp64; interior point with shifted-restart + elastic restoration and penalty escalation, block-structured interval evaluation, LDS-staged wave-cooperative Riccati, data re-packing)"; }
 
 void ltompc_default_params(ltompc_params* p) {
   std::memset(p, 0, sizeof *p);
@@ -273,6 +273,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
+  o->resto_rho_max = 1e7, o->resto_rho_factor = 1e4, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
@@ -289,6 +290,9 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (params->ell_penalty > 0 && (!(params->ell_D_f > 0) || !(params->ell_D_r > 0) || !std::isfinite(params->ell_rho)))
     return fail("ltompc_create: friction-ellipse constraints need ell_D_f > 0, ell_D_r > 0 and a finite ell_rho");
   if (options->resto_sticky < 0) return fail("ltompc_create: resto_sticky must be >= 0");
+  if (!std::isfinite(options->resto_rho_max) || !std::isfinite(options->resto_rho_factor) || options->resto_rho_factor < 0)
+    return fail("ltompc_create: resto_rho_max and resto_rho_factor must be finite, resto_rho_factor >= 0 (<= 1: no penalty escalation)");
+  if (options->warm_fallback_iter < 0) return fail("ltompc_create: warm_fallback_iter must be >= 0 (0 = off)");
   if (options->max_soc != 0) return fail("ltompc_create: max_soc must be 0 (the second-order correction exists in the oracle only, see include/ltompc.h)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)
     for (int i = 0; i < n_table; i++)
@@ -382,6 +386,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&h->d_act[0], Bp), rc |= h->dalloc(&h->d_act[1], Bp), rc |= h->dalloc(&h->d_nact[0], 4), rc |= h->dalloc(&h->d_nact[1], 4);
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
+  rc |= h->dalloc(&W.BK, 18 * N * Bp, true);  // starting point of the current solve (options.resto_shift_retry)
   rc |= h->dalloc(&h->d_counts, 16), rc |= h->dalloc(&h->d_roll, 2 * ltompc_solver::ROLL_RING);
   rc |= h->dalloc(&h->d_plist, (size_t)ltompc_solver::ROLL_RING * h->Bp);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
@@ -394,6 +399,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     ltompc_destroy(h);
     return fail("hipHostMalloc failed");
   }
+  W.orig = (gptr<const int>)h->d_orig;  // identity whenever the instances are not packed
+  hipLaunchKernelGGL(k_act_identity, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, h->B);
   if (hipMemcpyAsync(h->d_tables, tables, sizeof(double) * LTOMPC_TABLE_ROWS * n_table, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess) {
     ltompc_destroy(h);
@@ -462,6 +469,7 @@ int ltompc_set_initial_guess_dev(ltompc_handle h, const double* x0_dev) {
   if (!h || !x0_dev) return fail("ltompc_set_initial_guess: null argument");
   HIPCHECK(hipSetDevice(h->device));
   h->packed = false;  // a cold start overwrites the whole iterate: nothing to restore
+  hipLaunchKernelGGL(k_act_identity, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->d_orig, h->d_perm, h->B);  // (slot -> caller's index: identity again)
   hipLaunchKernelGGL(k_load_x0, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W, x0_dev, (const int*)nullptr, 0, 0);
   hipLaunchKernelGGL(k_zero_uprev, dim3((h->B + 63) / 64), dim3(64), 0, h->stream, h->W);
   hipLaunchKernelGGL(k_init, dim3((h->N * h->Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, 1);
@@ -618,8 +626,29 @@ int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation) {
   HIPCHECK(hipStreamSynchronize(h->stream));
   for (int b = 0; b < h->B; b++) {
     if (n_resto) n_resto[b] = si[(size_t)SI_NRESTO * h->Bp + b];
-    // (meaningful while the elastic variables exist: 0 once the solve is back on the hard constraints)
-    if (violation) violation[b] = st[(size_t)ST_RHO * h->Bp + b] > 0.0 ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
+    // (meaningful while the elastic variables exist: 0 once the solve is back on the hard constraints; g(x0) when the
+    //  node-0 rule decided the status)
+    if (violation) violation[b] = (st[(size_t)ST_RHO * h->Bp + b] > 0.0 || si[(size_t)SI_NODE0 * h->Bp + b]) ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
+  }
+  return 0;
+}
+
+int ltompc_get_recovery(ltompc_handle h, int* n_shift, int* n_fallback, double* g0, int* solver_status, double* penalty) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  if (ensure_unpacked(h)) return -1;
+  std::vector<int> si((size_t)SI_NF * h->Bp);
+  std::vector<double> st((size_t)ST_NF * h->Bp);
+  HIPCHECK(hipMemcpyAsync(si.data(), h->W.si, si.size() * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipMemcpyAsync(st.data(), h->W.st, st.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  for (int b = 0; b < h->B; b++) {
+    if (n_shift) n_shift[b] = si[(size_t)SI_NSHIFT * h->Bp + b];
+    if (n_fallback) n_fallback[b] = si[(size_t)SI_NFALLBACK * h->Bp + b];
+    if (g0) g0[b] = st[(size_t)ST_G0 * h->Bp + b];
+    const int node0 = si[(size_t)SI_NODE0 * h->Bp + b];
+    if (solver_status) solver_status[b] = node0 ? node0 - 1 : si[(size_t)SI_STATUS * h->Bp + b];
+    if (penalty) penalty[b] = st[(size_t)ST_RHO * h->Bp + b];
   }
   return 0;
 }

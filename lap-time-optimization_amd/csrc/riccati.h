@@ -5,6 +5,48 @@
 
 namespace ltompc {
 
+// ------------------------------------------------------------------------------------------ decisions of the head
+// Shared by the three Riccati kernels (one writer per instance calls them).
+//
+// Node-0 rule (options.node0_check): do_mpc registers the track constraints at node 0 too (controller.py:69-70); they only
+// involve the measured state, so they cannot change the minimiser, but a measured state outside the band leaves the
+// reference's NLP without a feasible point.  A converged status becomes INFEASIBLE (ST_VIOL = g(x0)) when g(x0) >
+// acceptable_tol, SOLVED becomes ACCEPTABLE when tol < g(x0) (IPOPT's error cannot fall below it).
+__device__ __forceinline__ int node0_rule(const ltompc_options& o, const double g0, const int term, int& node0) {
+  node0 = 0;
+  if (!o.node0_check || o.soft_rho > 0.0 || !(term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) return term;
+  if (g0 > o.acceptable_tol) {
+    node0 = term + 1;
+    return LTOMPC_STATUS_INFEASIBLE;
+  }
+  return g0 > o.tol ? LTOMPC_STATUS_ACCEPTABLE : term;
+}
+// The solve of instance b starts again from its current primal point (the next evaluation kernel re-initialises the slots:
+// SI_REINIT): slacks / multipliers / elastic variables for penalty `rho`, equality multipliers 0, barrier at mu_init (in the
+// units of the penalty scale), filter and regularisation history dropped.  This launch does no sweep for the instance.
+// Used by the penalty escalation of the restoration phase and by the fallback of a tuned warm start; d_pick has the same
+// block for the entry of the restoration phase.
+__device__ __forceinline__ void restart_from_primal(const Consts& K, const Work& W, const int b, const double rho) {
+  double* st = W.st;
+  int* si = W.si;
+  const ltompc_options& o = K.o;
+  const double mu0 = o.mu_init * pen_scale(rho);
+  const double eps = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * o.mu_init) : 0.0;
+  STD(ST_RHO) = rho, STD(ST_MU) = mu0, STD(ST_EPS_NEXT) = eps;
+  if (eps != STD(ST_EPS)) {  // (d_pick, which switches the smoothing otherwise, does not see the instance in this launch)
+    STD(ST_EPS) = eps;
+    double x0[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) x0[q] = W.x0[(size_t)q * W.Bp + b];
+    STD(ST_C00) = cost_eval(K.p, K.T, eps, x0, false, nullptr, nullptr);
+  }
+  STI(SI_REINIT) = 1;
+  STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+  STD(ST_DW_LAST) = 0.0, STD(ST_FORCE_REG) = 0.0;
+  STI(SI_NTINY) = 0, STI(SI_NACC) = 0, STI(SI_SINCEMU) = 0;
+  STI(SI_STEP) = 0, STI(SI_SKIP_EVAL) = 0;
+}
+
 // ------------------------------------------------------------------------------------------ k_riccati
 // One thread per instance.  State of the recursion is (x_k, v_k = u_{k-1}) because do_mpc's rterm penalises
 // u_k - u_{k-1} (controller.py:40-41): stage cost r |u_k - v_k|^2, v_{k+1} = u_k.
@@ -31,12 +73,13 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   }
   const int n_mult = N * (2 * NX + K.bd.ni) - (3 + K.bd.nel) + (STD(ST_RHO) > 0.0 ? 3 * (N - 1) : 0) + K.bd.nel * (N - 1);  // multipliers counted (last slot has no nl constraints; elastic pairs count twice)
   double mu = STD(ST_MU);
-  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
-  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  const double rho = STD(ST_RHO), S = pen_scale(rho), iS = 1.0 / S;  // penalty scale (layout.h): 1 unless rho > RHO_UNIT
+  double s_d = fmax(o.s_max, smult * iS / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd * iS / s_d, rp), cmax * iS / s_d);
   double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  double Emu = fmax(fmax(rd * iS / s_d, rp), rcmu * iS / s_d);
   STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = emax;
-  STI(SI_REINIT) = 0;
+  STI(SI_REINIT) = 0, STI(SI_SHIFT) = 0;
   int iters = STI(SI_ITERS);
   int passes = STI(SI_SWEEPS);  // (see layout.h: this kernel repeats failed sweeps inside the launch, each one a pass)
   if (passes > o.max_iter) {
@@ -61,35 +104,59 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
       STI(SI_RESTO) = 2, STD(ST_RHO) = 0.0;
       STI(SI_NACC) = 0, STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
       STI(SI_STEP) = 0, STI(SI_SKIP_EVAL) = 0;
-      atomicAdd(&W.active[it_index], 1);
+      if (it_index >= 0) atomicAdd(&W.active[it_index], 1);
+      return;
+    }
+    if (o.resto_rho_factor > 1.0 && rho < o.resto_rho_max) {  // penalty escalation, see d_head8
+      restart_from_primal(K, W, b, fmin(rho * o.resto_rho_factor, o.resto_rho_max));
+      STI(SI_NRESTO) += 1;
+      if (it_index >= 0) atomicAdd(&W.active[it_index], 1);
       return;
     }
     term = LTOMPC_STATUS_INFEASIBLE;
+  }
+  {
+    int node0;
+    term = node0_rule(o, STD(ST_G0), term, node0);
+    if (node0) STI(SI_NODE0) = node0, STD(ST_VIOL) = STD(ST_G0);
   }
   if (term >= 0) {
     STI(SI_STATUS) = term, STI(SI_DONE) = 1;
     return;
   }
-  atomicAdd(&W.active[it_index], 1);
-  // ---- monotone barrier update (IPOPT eq. (7)) ----
+  if (it_index >= 0) atomicAdd(&W.active[it_index], 1);
+  // ---- monotone barrier update (IPOPT eq. (7)), in the units of the penalty scale ----
   bool mu_changed = false;
-  while (Emu <= o.kappa_eps * mu && mu > o.mu_min) {
-    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-    mu_changed = true;
-    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  {
+    double mus = mu * iS;
+    while (Emu <= o.kappa_eps * mus && mus > o.mu_min) {
+      mus = fmax(o.mu_min, fmin(o.kappa_mu * mus, pow(mus, o.theta_mu)));
+      mu = mus * S;
+      mu_changed = true;
+      rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+      Emu = fmax(fmax(rd * iS / s_d, rp), rcmu * iS / s_d);
+    }
   }
   if (mu_changed) {
     STD(ST_MU) = mu;
-    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
+    STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * (mu * iS)) : 0.0;
     STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
   }
-  STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
+  {  // options.warm_fallback_iter, see d_head8
+    const int since = mu_changed ? 0 : STI(SI_SINCEMU) + 1;
+    STI(SI_SINCEMU) = since;
+    if (STI(SI_FBARMED) && since >= o.warm_fallback_iter) {
+      STI(SI_FBARMED) = 0, STI(SI_NFALLBACK) += 1;
+      restart_from_primal(K, W, b, rho);
+      return;
+    }
+  }
+  STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu * iS);
   // ---- backward sweep, retried with Hessian regularisation until every Huu is positive definite ----
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
   double delta_w = STD(ST_FORCE_REG);
   const double dw_last = STD(ST_DW_LAST);
-  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  if (delta_w == 0.0 && dw_last > DW_KEEP * S) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
   int tries = 0;
   bool numerical = false;
   for (;;) {
@@ -242,7 +309,7 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     }
     if (ok) break;
     // inertia correction schedule (Waechter & Biegler 2006, Algorithm IC)
-    if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+    if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first * S : fmax(1e-20, dw_last / 3.0);
     else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
     STI(SI_NREG) += 1;
     if (++tries > 40 || delta_w > 1e20) {
@@ -259,8 +326,8 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
     return;
   }
-  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
-  else if (dw_last <= DW_KEEP) STD(ST_DW_LAST) = 0.0;
+  if (delta_w > 0.0) STD(ST_DW_LAST) = delta_w > DW_KEEP * S ? delta_w : 0.0;
+  else if (dw_last <= DW_KEEP * S) STD(ST_DW_LAST) = 0.0;
   STD(ST_DW) = delta_w;
   // ---- forward rollout ----
   double dx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dv[2] = {0, 0};
@@ -342,12 +409,14 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
   }
   const int n_mult = N * (2 * NX + K.bd.ni) - (3 + K.bd.nel) + (rho > 0.0 ? 3 * (N - 1) : 0) + K.bd.nel * (N - 1);  // multipliers counted (the last slot has no nonlinear constraints; elastic pairs count twice)
   mu = STD(ST_MU);
-  double s_d = fmax(o.s_max, smult / n_mult) / o.s_max;
-  double E0 = fmax(fmax(rd / s_d, rp), cmax / s_d);
+  const double S = pen_scale(rho), iS = 1.0 / S;  // penalty scale (layout.h): 1 unless rho > RHO_UNIT
+  double s_d = fmax(o.s_max, smult * iS / n_mult) / o.s_max;
+  double E0 = fmax(fmax(rd * iS / s_d, rp), cmax * iS / s_d);
   double rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-  double Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
+  double Emu = fmax(fmax(rd * iS / s_d, rp), rcmu * iS / s_d);
   int term = -1;
-  bool to_hard = false;
+  bool to_hard = false, escalate = false, fallback = false;
+  if (valid && i == 0 && STI(SI_REINIT)) STI(SI_REINIT) = 0, STI(SI_SHIFT) = 0;  // the evaluation before this head has re-initialised the slots
   if (live && !retry) {
     int iters = STI(SI_ITERS);
     if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
@@ -366,15 +435,28 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
       // locally: a stationary point of the infeasibility.
       const double e_tol = term == LTOMPC_STATUS_SOLVED ? o.tol : o.acceptable_tol;
       if (emax <= e_tol) to_hard = true, term = -1;
+      // Some elastic variable stays > tol: at THIS penalty violating is cheaper than complying (that constraint's multiplier
+      // sits at the penalty), which a feasible NLP with multipliers > rho shows as well.  The penalty of this instance goes up
+      // (options.resto_rho_factor, in one step to resto_rho_max by default) and the elastic problem is solved again from the
+      // current primal point, re-centred as at the entry of the phase; INFEASIBLE only at the largest penalty: a stationary
+      // point of objective / resto_rho_max + violation.
+      else if (o.resto_rho_factor > 1.0 && rho < o.resto_rho_max) escalate = true, term = -1;
       else term = LTOMPC_STATUS_INFEASIBLE;
     }
+    int node0;
+    term = node0_rule(o, STD(ST_G0), term, node0);
     if (i == 0) {
-      STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = emax;
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = node0 ? STD(ST_G0) : emax;
+      if (node0) STI(SI_NODE0) = node0;
       if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
       if (to_hard) {
         STI(SI_RESTO) = 2, STD(ST_RHO) = 0.0;
         STI(SI_NACC) = 0, STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
         STI(SI_STEP) = 0, STI(SI_SKIP_EVAL) = 0;
+      }
+      if (escalate) {
+        restart_from_primal(K, W, b, fmin(rho * o.resto_rho_factor, o.resto_rho_max));
+        STI(SI_NRESTO) += 1;
       }
     }
     if (term >= 0) live = false;
@@ -384,27 +466,43 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     live = false;
   }
   if (live && i == 0) STI(SI_SWEEPS) = passes + 1;
-  if (valid && i == 0 && STI(SI_REINIT)) STI(SI_REINIT) = 0;  // the evaluation before this head has re-initialised the slots
   if (live && i == 0 && active_slot >= 0) atomicAdd(&W.active[active_slot], 1);
-  if (to_hard) live = false;  // (counted as unfinished above)
+  if (to_hard || escalate) live = false;  // (counted as unfinished above)
   if (!__any(live)) return false;
-  // ---- monotone barrier update
+  // ---- monotone barrier update, in the units of the penalty scale
   bool mu_changed = false;
-  while (live && !retry && Emu <= o.kappa_eps * mu && mu > o.mu_min) {
-    mu = fmax(o.mu_min, fmin(o.kappa_mu * mu, pow(mu, o.theta_mu)));
-    mu_changed = true;
-    rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
-    Emu = fmax(fmax(rd / s_d, rp), rcmu / s_d);
-  }
-  if (live && !retry && i == 0) {
-    if (mu_changed) {
-      STD(ST_MU) = mu;
-      STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * mu) : 0.0;
-      STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+  {
+    double mus = mu * iS;
+    while (live && !retry && Emu <= o.kappa_eps * mus && mus > o.mu_min) {
+      mus = fmax(o.mu_min, fmin(o.kappa_mu * mus, pow(mus, o.theta_mu)));
+      mu = mus * S;
+      mu_changed = true;
+      rcmu = fmax(fabs(cmax - mu), fabs(cmin - mu));
+      Emu = fmax(fmax(rd * iS / s_d, rp), rcmu * iS / s_d);
     }
-    STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu);
   }
-  return true;
+  if (live && !retry) {
+    // options.warm_fallback_iter: a solve that started at the small barrier parameter of a tuned warm start (mu_init_warm) and has
+    // not decreased it for that many iterations is cycling around a point that is not central; once per solve it starts again
+    // from its current primal point the way a solve after a failed one starts (multipliers 0, barrier at mu_init)
+    const int since = mu_changed ? 0 : STI(SI_SINCEMU) + 1;
+    fallback = STI(SI_FBARMED) && since >= o.warm_fallback_iter;
+    if (i == 0) {
+      STI(SI_SINCEMU) = since;
+      if (mu_changed) {
+        STD(ST_MU) = mu;
+        STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * (mu * iS)) : 0.0;
+        STI(SI_NFILT) = 0, STD(ST_THETA0) = -1.0;
+      }
+      STD(ST_TAU) = fmax(o.tau_min, 1.0 - mu * iS);
+      if (fallback) {
+        STI(SI_FBARMED) = 0, STI(SI_NFALLBACK) += 1;
+        restart_from_primal(K, W, b, rho);
+      }
+    }
+    if (fallback) live = false;
+  }
+  return __any(live);
 }
 
 // ------------------------------------------------------------------------------------------ k_riccati8
@@ -442,9 +540,10 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
   // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
   //      the others recompute the same numbers)
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  const double psc = pen_scale(STD(ST_RHO));  // penalty scale (layout.h): the regularisation schedule in its units
   double delta_w = STD(ST_FORCE_REG);
   const double dw_last = STD(ST_DW_LAST);
-  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  if (delta_w == 0.0 && dw_last > DW_KEEP * psc) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
   int tries = 0;
   if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
   bool numerical = false;
@@ -667,7 +766,7 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
     const bool failed = live && !ok;
     if (failed) {
-      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first * psc : fmax(1e-20, dw_last / 3.0);
       else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
       if (++tries > 40 || delta_w > 1e20) numerical = true;
       if (i == 0) STI(SI_NREG) += 1;
@@ -686,7 +785,7 @@ __device__ __forceinline__ void d_riccati8(const Consts& K, const Work& W, RicLd
     if (!__any(again)) break;
   }
   if (live && i == 0) {
-    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+    STD(ST_DW_LAST) = delta_w > DW_KEEP * psc ? delta_w : 0.0;
     STD(ST_DW) = delta_w;
     STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
     STI(SI_STEP) = 1;
@@ -815,9 +914,10 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   // ---- backward sweep (whole wave in lock-step; an instance whose Huu fails retries with a larger delta_w,
   //      the others recompute the same numbers)
   const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  const double psc = pen_scale(STD(ST_RHO));  // penalty scale (layout.h): the regularisation schedule in its units
   double delta_w = STD(ST_FORCE_REG);
   const double dw_last = STD(ST_DW_LAST);
-  if (delta_w == 0.0 && dw_last > DW_KEEP) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+  if (delta_w == 0.0 && dw_last > DW_KEEP * psc) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
   int tries = 0;
   if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
   bool numerical = false;
@@ -1012,7 +1112,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
     const bool failed = live && !ok;
     if (failed) {
-      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first : fmax(1e-20, dw_last / 3.0);
+      if (delta_w == 0.0) delta_w = dw_last == 0.0 ? o.delta_w_first * psc : fmax(1e-20, dw_last / 3.0);
       else delta_w *= (dw_last == 0.0 ? 100.0 : 8.0);
       if (++tries > 40 || delta_w > 1e20) numerical = true;
       if (i == 0) STI(SI_NREG) += 1;
@@ -1032,7 +1132,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
   }
   RTOCK(2);
   if (live && i == 0) {
-    STD(ST_DW_LAST) = delta_w > DW_KEEP ? delta_w : 0.0;
+    STD(ST_DW_LAST) = delta_w > DW_KEEP * psc ? delta_w : 0.0;
     STD(ST_DW) = delta_w;
     STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
     STI(SI_STEP) = 1;

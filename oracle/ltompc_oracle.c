@@ -159,7 +159,7 @@ static tables_t tables_view(const double* packed, int n) {
 static int lut_interval(const double* grid, int n, double s) {
   double inv = (double)(n - 1) / (grid[n - 1] - grid[0]);
   double fi = (s - grid[0]) * inv;
-  int i = fi <= 0 ? 0 : (fi >= n - 2 ? n - 2 : (int)fi);
+  int i = !(fi > 0) ? 0 : (fi >= n - 2 ? n - 2 : (int)fi); /* (NaN -> 0) */
   while (i > 0 && s < grid[i]) i--;
   while (i < n - 2 && s >= grid[i + 1]) i++;
   return i;
@@ -674,14 +674,18 @@ typedef struct {
 
 typedef struct {
   int status, iters;
+  int status_solver; /* the solver's own termination status, before the node-0 rule (options.node0_check): what decides how the next
+                        solve is warm-started (warm_reset_on_fail, resto_sticky) */
   double kkt, obj, mu;
-  int n_reg, n_lsfail, n_soc, n_resto;
-  double viol; /* largest elastic variable at termination (0 on the hard constraints) */
+  int n_reg, n_lsfail, n_soc, n_resto, n_fallback, n_shift;
+  double viol; /* largest elastic variable at termination (0 on the hard constraints); g0 when node 0 decided the status */
+  double g0;   /* largest track constraint at the measured state (options.node0_check) */
 } solve_stats;
 
 #define FILTER_MAX 64
 #define ELASTIC_CP_VIOL 0.1 /* [m] violation of a track constraint above which its elastic variable starts on the central path */
 #define DW_KEEP 1e-5
+#define RHO_UNIT 1000.0 /* penalty of the elastic variables at which the solve runs unscaled (IPOPT's restoration penalty), see S in solve_one */
 
 /* everything one solve works on */
 typedef struct {
@@ -1054,9 +1058,9 @@ static void init_slacks(ipws* s) {
 static int solve_one(const ltompc_params* p, const ltompc_options* o, const tables_t* T0, int N, const double* x0,
                      const double* uprev, int warm, int start_elastic, double* X, double* C, double* U, double* L1, double* L2,
                      double* Tout, double* NUout, solve_stats* st) {
-  ipws S;
-  ipws* s = &S;
-  memset(s, 0, sizeof S);
+  ipws WS;
+  ipws* s = &WS;
+  memset(s, 0, sizeof WS);
   s->p = p, s->o = o, s->N = N, s->hdt = o->t_step, s->uprev = uprev;
   build_bounds(p, &s->bd);
   const bounds_t* bd = &s->bd;
@@ -1110,11 +1114,17 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     memcpy(it->x, x0, sizeof(double) * NX); /* node 0 is the measured state */
     if (warm == 2) memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
   }
+  /* the solve's own starting point (options.resto_shift_retry) */
+  double* Xw = malloc(sizeof(double) * ((size_t)(N + 1) * NX + (size_t)N * NX + (size_t)N * NU));
+  double *Cw = Xw + (size_t)(N + 1) * NX, *Uw = Cw + (size_t)N * NX;
+  memcpy(Xw, it->x, sizeof(double) * (size_t)(N + 1) * NX), memcpy(Cw, it->c, sizeof(double) * (size_t)N * NX);
+  memcpy(Uw, it->u, sizeof(double) * (size_t)N * NU);
   double mu = (warm == 1 && o->mu_init_warm > 0) ? o->mu_init_warm : o->mu_init;
-  s->mu = mu;
   Tl.eps_s = SMOOTHING(mu);
+  mu *= (o->soft_rho > RHO_UNIT ? o->soft_rho / RHO_UNIT : 1.0); /* (penalty scale S below: soft_rho > RHO_UNIT runs in scaled units) */
+  s->mu = mu;
   init_slacks(s);
-  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0;
+  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0, st->n_fallback = 0, st->n_shift = 0;
 
   /* filter */
   double filt_th[FILTER_MAX], filt_ph[FILTER_MAX];
@@ -1126,15 +1136,27 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   double force_reg = 0.0;
   /* restoration (elastic mode): 0 = not entered, 1 = solving the elastic problem, 2 = back on the hard constraints */
   int resto = 0;
+  /* Penalty scale of the restoration phase (escalation, include/ltompc.h resto_rho_max): the elastic problem is
+   * f + S resto_rho violation, and everything that has the units of the objective - KKT tolerances, barrier parameter,
+   * regularisation, the objective side of the filter - is taken in the units of  f / S + resto_rho violation,  the problem
+   * the solver already handles at S = 1 (at S = 1e4 the unscaled tolerance 1e-8 on gradients of size 1e7 is below the
+   * rounding floor).  S = 1 outside an escalated restoration: x / 1.0 and x * 1.0 are exact, nothing changes there. */
+#define PEN_SCALE(rho_) ((rho_) > RHO_UNIT ? (rho_) / RHO_UNIT : 1.0)
+  double S = PEN_SCALE(it->rho); /* (soft_rho) */
   const int resto_allowed = o->resto_rho > 0 && !(o->soft_rho > 0);
   if (start_elastic && resto_allowed && warm) { /* (slacks and elastic variables below: init_slacks with rho = resto_rho) */
     resto = 1, st->n_resto = 1;
     it_set_rho(it, o->resto_rho, p), it_set_rho(tr, o->resto_rho, p);
+    S = PEN_SCALE(it->rho);
+    mu = s->mu = mu * S; /* (the barrier parameter chosen above is in scaled units; soft_rho = 0 here) */
     init_slacks(s);
   }
 
   double eps_next = Tl.eps_s;
   int n_tiny = 0;
+  /* options.warm_fallback_iter: iterations since the barrier parameter last decreased, in a solve that started at mu_init_warm */
+  int shift_retried = 0;
+  int since_mu = 0, fallback_armed = (warm == 1 && o->mu_init_warm > 0 && o->warm_fallback_iter > 0);
   for (iter = 0;; iter++) {
     /* table smoothing follows the barrier parameter with a lag of one iteration (so that one linearisation
      * serves the whole iteration, also when mu is reduced in it); the filter restarts when it changes */
@@ -1190,9 +1212,9 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           }
         }
     }
-    double s_d = fmax(o->s_max, sum_mult / n_mult) / o->s_max;
-    E0 = fmax(fmax(rd / s_d, rp), rc_0 / s_d);
-    double Emu = fmax(fmax(rd / s_d, rp), rc_mu / s_d);
+    double s_d = fmax(o->s_max, sum_mult / S / n_mult) / o->s_max;
+    E0 = fmax(fmax(rd / S / s_d, rp), rc_0 / S / s_d);
+    double Emu = fmax(fmax(rd / S / s_d, rp), rc_mu / S / s_d);
     int term = -1;
     if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
     else if (E0 <= o->tol) term = LTOMPC_STATUS_SOLVED;
@@ -1209,9 +1231,28 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       const double e_tol = term == LTOMPC_STATUS_SOLVED ? o->tol : o->acceptable_tol;
       if (e_max <= e_tol) {
         resto = 2, it_set_rho(it, 0.0, p), it_set_rho(tr, 0.0, p);
+        S = 1.0; /* (the barrier parameter stays where it is, mu_min * S_old or above: the hard problem goes on from there) */
         n_acc = 0, nfilt = 0, theta0 = -1;
         if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d elastic problem converged, e_max %.2e: back to the hard constraints\n", iter, e_max);
         iter--; /* (this pass only switched the problem: not an iteration) */
+        continue;
+      }
+      /* Some elastic variable stays > tol: at THIS penalty violating is cheaper than complying (that constraint's multiplier
+       * sits at the penalty), which a feasible NLP with multipliers > rho shows as well.  Escalate the penalty of this
+       * instance and solve the elastic problem again from the current primal point (re-centred exactly as at the entry of the
+       * phase); INFEASIBLE only at the largest penalty: a stationary point of objective / rho_max + violation. */
+      if (o->resto_rho_factor > 1.0 && it->rho < o->resto_rho_max) {
+        const double rho_new = fmin(it->rho * o->resto_rho_factor, o->resto_rho_max);
+        if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d elastic problem converged with e_max %.2e at rho %.0e: penalty -> %.0e\n", iter, e_max, it->rho, rho_new);
+        it_set_rho(it, rho_new, p), it_set_rho(tr, rho_new, p);
+        S = PEN_SCALE(rho_new);
+        memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
+        mu = s->mu = o->mu_init * S;
+        Tl.eps_s = eps_next = SMOOTHING(mu / S);
+        init_slacks(s);
+        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+        st->n_resto++;
+        iter--; /* (this pass only changed the problem: not an iteration) */
         continue;
       }
       term = LTOMPC_STATUS_INFEASIBLE;
@@ -1219,10 +1260,10 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     if (term >= 0) { status = term; break; }
     /* ---- barrier update (monotone, IPOPT eq. (7)); slot derivatives depend on mu only via gradients ---- */
     int mu_changed = 0;
-    while (Emu <= o->kappa_eps * mu && mu > o->mu_min) {
-      double mn = fmax(o->mu_min, fmin(o->kappa_mu * mu, pow(mu, o->theta_mu)));
-      mu = mn, mu_changed = 1;
-      Emu = fmax(fmax(rd / s_d, rp), 0.0);
+    while (Emu <= o->kappa_eps * (mu / S) && mu / S > o->mu_min) {
+      double mn = fmax(o->mu_min, fmin(o->kappa_mu * (mu / S), pow(mu / S, o->theta_mu)));
+      mu = mn * S, mu_changed = 1;
+      Emu = fmax(fmax(rd / S / s_d, rp), 0.0);
       double rcm = 0;
       for (int k = 0; k < N; k++)
         for (int m = 0; m < ni; m++)
@@ -1231,15 +1272,30 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
             const int q = m - (ni - bd->nnl);
             if (q >= 0 && it->pen[q] > 0) rcm = fmax(rcm, fabs(it->e[k * NNLT + q] * (it->pen[q] - it->nu[k * MAXI + m]) - mu));
           }
-      Emu = fmax(Emu, rcm / s_d);
+      Emu = fmax(Emu, rcm / S / s_d);
     }
     s->mu = mu;
+    since_mu = mu_changed ? 0 : since_mu + 1;
+    if (fallback_armed && since_mu >= o->warm_fallback_iter) {
+      /* the solve started at the small barrier parameter of a tuned warm start and is going nowhere: once, start again
+       * from the current primal point the way a solve after a failed one starts (multipliers 0, barrier at mu_init) */
+      fallback_armed = 0, since_mu = 0;
+      memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
+      mu = s->mu = o->mu_init * S;
+      Tl.eps_s = eps_next = SMOOTHING(mu / S);
+      init_slacks(s);
+      nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+      st->n_fallback++;
+      if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d no barrier update for %d iterations after a tuned warm start: restart at mu_init\n", iter, o->warm_fallback_iter);
+      iter--; /* (this pass only re-initialised the point: not an iteration) */
+      continue;
+    }
     if (mu_changed) {
-      eps_next = SMOOTHING(mu);
+      eps_next = SMOOTHING(mu / S);
       for (int k = 0; k < N; k++) slot_gradients(bd, it, k, mu, &L[k]);
       nfilt = 0, theta0 = -1; /* filter reset */
     }
-    double tau = fmax(o->tau_min, 1.0 - mu);
+    double tau = fmax(o->tau_min, 1.0 - mu / S);
 
     /* ---- condensing of the collocation point ---- */
     for (int k = 0; k < N; k++) {
@@ -1253,11 +1309,11 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
      * DW_KEEP the first attempt already uses delta_w_last / 3 instead of 0 (every attempt is a full sweep here;
      * this halves the number of sweeps at the same iteration counts).  delta_w decays by 3 per iteration and
      * returns to exactly 0 below DW_KEEP, so the final Newton iterations are unregularised. */
-    if (delta_w == 0.0 && delta_w_last > DW_KEEP) delta_w = delta_w_last / 3.0;
+    if (delta_w == 0.0 && delta_w_last > DW_KEEP * S) delta_w = delta_w_last / 3.0;
     int tries = 0;
     while (!riccati_sweep(s, delta_w, 0)) {
       /* IPOPT-style inertia correction schedule (Waechter-Biegler Alg. IC) */
-      if (delta_w == 0.0) delta_w = delta_w_last == 0.0 ? o->delta_w_first : fmax(1e-20, delta_w_last / 3.0);
+      if (delta_w == 0.0) delta_w = delta_w_last == 0.0 ? o->delta_w_first * S : fmax(1e-20, delta_w_last / 3.0);
       else delta_w *= (delta_w_last == 0.0 ? 100.0 : 8.0);
       st->n_reg++;
       if (++tries > 40 || delta_w > 1e20) {
@@ -1266,7 +1322,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       }
     }
     if (delta_w > 0) delta_w_last = delta_w;
-    if (delta_w_last <= DW_KEEP) delta_w_last = 0.0;
+    if (delta_w_last <= DW_KEEP * S) delta_w_last = 0.0;
 
     forward_recover(s, delta_w);
     if (getenv("ORACLE_CHECK")) { /* residual of the linear KKT system the sweep is supposed to solve */
@@ -1322,15 +1378,15 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     for (int f = 0; f < nfilt; f++)                                                                             \
       if (th >= filt_th[f] && ph >= filt_ph[f]) { in_filter_ = 1; break; }                                      \
     if (in_filter_) break;                                                                                      \
-    int sw_ = (gphi_d < 0) && ((a_test) * pow(-gphi_d, s_ph) > dlt * pow(th0, s_th));                           \
+    int sw_ = (gphi_d < 0) && ((a_test) * pow(-gphi_d / S, s_ph) > dlt * pow(th0, s_th));                       \
     int armijo_ = ph <= ph0 + eta_ph * (a_test) * gphi_d;                                                       \
     int ok_;                                                                                                    \
     if (th0 <= theta_min && sw_) ok_ = armijo_;                                                                 \
-    else ok_ = (th <= (1 - g_th) * th0) || (ph <= ph0 - g_ph * th0);                                            \
+    else ok_ = (th <= (1 - g_th) * th0) || (ph <= ph0 - g_ph * S * th0);                                        \
     if (!ok_) break;                                                                                            \
     if (!(sw_ && armijo_)) { /* augment filter */                                                               \
       if (nfilt == FILTER_MAX) { memmove(filt_th, filt_th + 1, sizeof(double) * (FILTER_MAX - 1)); memmove(filt_ph, filt_ph + 1, sizeof(double) * (FILTER_MAX - 1)); nfilt--; } \
-      filt_th[nfilt] = (1 - g_th) * th0, filt_ph[nfilt] = ph0 - g_ph * th0, nfilt++;                            \
+      filt_th[nfilt] = (1 - g_th) * th0, filt_ph[nfilt] = ph0 - g_ph * S * th0, nfilt++;                        \
     }                                                                                                           \
     ok_out = 1;                                                                                                 \
   } while (0)
@@ -1402,6 +1458,32 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       st->n_lsfail++;
       if (resto_allowed && resto == 0) {
       enter_resto:
+        if (warm && !o->warm_shift && o->resto_shift_retry && !shift_retried) {
+          /* ---- first remedy: the jam may be the un-shifted warm start's doing (do_mpc re-uses the previous solution as it
+           *      is, one interval behind the new measured state; measured on the reference's own loop: two of the seven ticks
+           *      that ended INFEASIBLE in round 2 are solved in 14 iterations from the shifted point).  Once per solve: start
+           *      again on the hard constraints from the solve's own starting point moved one interval ahead (options.warm_shift's
+           *      rule: last interval repeated), multipliers 0, barrier at mu_init.  The restoration phase proper follows if
+           *      this start jams too. */
+          shift_retried = 1, st->n_shift++;
+          for (int k = 0; k + 1 < N; k++) {
+            memcpy(it->x + k * NX, Xw + (k + 1) * NX, sizeof(double) * NX);
+            memcpy(it->c + k * NX, Cw + (k + 1) * NX, sizeof(double) * NX);
+            memcpy(it->u + k * NU, Uw + (k + 1) * NU, sizeof(double) * NU);
+          }
+          memcpy(it->x + (N - 1) * NX, Xw + N * NX, sizeof(double) * NX);
+          memcpy(it->x + N * NX, Xw + N * NX, sizeof(double) * NX);
+          memcpy(it->c + (N - 1) * NX, Cw + (N - 1) * NX, sizeof(double) * NX);
+          memcpy(it->u + (N - 1) * NU, Uw + (N - 1) * NU, sizeof(double) * NU);
+          memcpy(it->x, x0, sizeof(double) * NX);
+          memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
+          mu = s->mu = o->mu_init;
+          Tl.eps_s = eps_next = SMOOTHING(mu);
+          init_slacks(s);
+          nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+          if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d -> start again from the shifted warm start\n", iter);
+          continue;
+        }
         /* ---- restoration phase, as an elastic mode: the track constraints get elastic variables that
          *      cost resto_rho each; equality multipliers, slacks and the barrier parameter start again at the current
          *      primal point.  (IPOPT: min rho ||c(x)||_1 + zeta/2 ||D(x - x_R)||^2 over all constraints, then back to
@@ -1409,9 +1491,10 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
          *      is the solution.) */
         resto = 1, st->n_resto++;
         it_set_rho(it, o->resto_rho, p), it_set_rho(tr, o->resto_rho, p);
+        S = PEN_SCALE(it->rho);
         memset(it->l1, 0, sizeof(double) * (size_t)N * NX), memset(it->l2, 0, sizeof(double) * (size_t)N * NX);
-        mu = s->mu = o->mu_init;
-        Tl.eps_s = eps_next = SMOOTHING(mu);
+        mu = s->mu = o->mu_init * S;
+        Tl.eps_s = eps_next = SMOOTHING(mu / S);
         init_slacks(s);
         nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
         if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d -> restoration (elastic mode, rho %.0f)\n", iter, o->resto_rho);
@@ -1420,7 +1503,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
       /* no (further) restoration: retry this iterate with a (larger) forced regularisation; after a few
        * failures take the smallest step and reset the filter so that the iteration cannot stall */
       if (o->max_ls_fail > 0 && st->n_lsfail >= o->max_ls_fail) { status = LTOMPC_STATUS_STALLED; break; }
-      if (force_reg < 1e4) { force_reg = force_reg == 0 ? 1e-2 : force_reg * 100; continue; }
+      if (force_reg < 1e4 * S) { force_reg = force_reg == 0 ? 1e-2 * S : force_reg * 100; continue; }
       nfilt = 0;
       alpha = a_pri * pow(0.5, o->n_linesearch - 1);
     }
@@ -1465,14 +1548,30 @@ done:
   if (Tout && NUout)
     for (int k = 0; k < N; k++)
       for (int m = 0; m < ni; m++) Tout[k * ni + m] = it->t[k * MAXI + m], NUout[k * ni + m] = it->nu[k * MAXI + m];
-  st->status = status, st->iters = iter, st->kkt = E0, st->obj = obj, st->mu = mu;
   st->viol = 0.0;
   if (it->rho > 0)
     for (int k = 0; k + 1 < N; k++)
       for (int q = 0; q < NNL; q++) st->viol = fmax(st->viol, it->e[k * NNLT + q]);
+  st->g0 = -INFINITY, st->status_solver = status;
+  if (o->node0_check && !(o->soft_rho > 0)) {
+    /* do_mpc registers the track constraints at node 0 as well (controller.py:69-70): rows that only involve the
+     * measured state.  They cannot change the minimiser, but a measured state outside the band leaves the reference's NLP
+     * without a feasible point: a converged status becomes INFEASIBLE (violation g(x0)); when the violation is below the
+     * acceptable level SOLVED becomes ACCEPTABLE (IPOPT's error cannot fall below it). */
+    tables_t Te = *T0;
+    Te.eps_s = SMOOTHING(0.0), Te.eps_mu = 0.0;
+    double g[NNL];
+    cons_val(p, &Te, x0, g);
+    st->g0 = fmax(g[0], fmax(g[1], g[2]));
+    if (status == LTOMPC_STATUS_SOLVED || status == LTOMPC_STATUS_ACCEPTABLE) {
+      if (st->g0 > o->acceptable_tol) status = LTOMPC_STATUS_INFEASIBLE, st->viol = st->g0;
+      else if (st->g0 > o->tol) status = LTOMPC_STATUS_ACCEPTABLE;
+    }
+  }
+  st->status = status, st->iters = iter, st->kkt = E0, st->obj = obj, st->mu = mu;
   it_free(it), it_free(tr);
   free(s->L), free(s->W), free(dx), free(dc), free(du), free(nl1), free(nl2), free(dt), free(dnu), free(de);
-  free(sG1), free(sG2), free(sR);
+  free(sG1), free(sG2), free(sR), free(Xw);
   return 0;
 }
 
@@ -1500,6 +1599,7 @@ void oracle_default_options(ltompc_options* o) {
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
+  o->resto_rho_max = 1e7, o->resto_rho_factor = 1e4, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
   o->warm_reset_on_fail = 1; /* applied by the caller (oracle.py solve(prev_status=...)): this file sees one solve at a time */
 }
 
@@ -1607,12 +1707,12 @@ int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const d
 
 /* Batched solve.  Arrays are batch-major: X: B x (N+1) x 8, C: B x N x 8, U: B x N x 2, L1/L2: B x N x 8
  * (in: warm start if warm != 0; out: solution).  stats: B x 5 doubles (status, iters, kkt, obj, mu) +
- * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol => 10 doubles per instance. */
+ * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol + g0 + n_fallback + n_shift + status_solver => 14 doubles per instance. */
 int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const double* tab, int nt, int N, int B,
                        const double* x0, const double* uprev, int warm, double* X, double* C, double* U,
                        double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout,
                        const int* prev_status, int* sticky) {
-  /* prev_status (may be NULL): status of the solve the warm start comes from, per instance (option warm_reset_on_fail).
+  /* prev_status (may be NULL): the solver's own status (stats[13]) of the solve the warm start comes from, per instance (option warm_reset_on_fail).
    * sticky (may be NULL; in/out): option resto_sticky, ticks for which an instance still starts in elastic mode. */
   bounds_t bd0;
   build_bounds(p, &bd0);
@@ -1641,13 +1741,13 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
       /* an instance that jammed on the hard constraints, or whose horizon problem is infeasible, starts its next
        * resto_sticky solves in elastic mode */
       const int jammed = st.n_resto > 0 && !start_elastic;
-      if (st.status == LTOMPC_STATUS_INFEASIBLE || jammed) sticky[b] = o->resto_sticky;
+      if (st.status_solver == LTOMPC_STATUS_INFEASIBLE || jammed) sticky[b] = o->resto_sticky;
       else if (sticky[b] > 0) sticky[b]--;
     }
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
-    double* s = stats + (size_t)b * 10;
+    double* s = stats + (size_t)b * 14;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;
-    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol;
+    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol, s[10] = st.g0, s[11] = st.n_fallback, s[12] = st.n_shift, s[13] = st.status_solver;
   }
   return 0;
 }

@@ -28,9 +28,11 @@ class Params(C.Structure):
 class Options(C.Structure):
     _fields_ = [(n, C.c_double) for n in (
         "t_step", "tol", "acceptable_tol", "mu_init", "mu_min", "kappa_eps", "kappa_mu", "theta_mu", "tau_min",
-        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho", "resto_rho")] + [
+        "bound_push", "s_max", "delta_w_first", "smooth_eps_min", "smooth_scale", "mu_init_warm", "soft_rho", "resto_rho",
+        "resto_rho_max", "resto_rho_factor")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
-        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("resto_sticky", C.c_int), ("latency_mode", C.c_int)]
+        ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("resto_sticky", C.c_int),
+        ("node0_check", C.c_int), ("warm_fallback_iter", C.c_int), ("resto_shift_retry", C.c_int), ("latency_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -125,11 +127,12 @@ class Oracle:
     # ---- NLP solve ----------------------------------------------------------------
     def solve(self, x0, N, uprev=None, warm=None, nthreads=0, prev_status=None, sticky=None):
         """x0: (B,8).  warm: dict(X,C,U,L1,L2) of a previous solve or None (do_mpc set_initial_guess).
-        prev_status: status of the solve `warm` comes from (option warm_reset_on_fail of include/ltompc.h: an instance
+        prev_status: status of the solve `warm` comes from - when `warm` is a result of this method its "status_solver" is used
+        (the solver's own termination status; "status" may be INFEASIBLE by the node-0 rule) - (option warm_reset_on_fail of include/ltompc.h: an instance
         whose previous solve did not converge keeps the primal point, restarts L1 = L2 = 0 and the barrier at mu_init).
         sticky: int32 array (B,), in/out: option resto_sticky (ticks for which an instance starts in elastic mode); the
         caller keeps it between ticks (the device library keeps it in the handle).
-        Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail, n_soc, n_resto, viol)."""
+        Returns dict(u0, X, C, U, L1, L2, status, iters, kkt, obj, mu, n_reg, n_lsfail, n_soc, n_resto, viol, g0, n_fallback)."""
         x0 = np.ascontiguousarray(np.atleast_2d(x0), float)
         B = x0.shape[0]
         uprev = np.zeros((B, 2)) if uprev is None else np.ascontiguousarray(np.atleast_2d(uprev), float)
@@ -138,11 +141,14 @@ class Oracle:
             L1, L2 = np.zeros((B, N, 8)), np.zeros((B, N, 8))
         else:
             X, Cc, U, L1, L2 = (np.ascontiguousarray(warm[k], float).copy() for k in ("X", "C", "U", "L1", "L2"))
-        u0, st = np.zeros((B, 2)), np.zeros((B, 10))
+        u0, st = np.zeros((B, 2)), np.zeros((B, 14))
         ni = int(lib().oracle_num_ineq(C.byref(self.p)))
         Tt, Nu = np.zeros((B, N, ni)), np.zeros((B, N, ni))
         ps = None
         if warm is not None and prev_status is not None:
+            # (what counts is how the solver itself ended, before the node-0 rule of options.node0_check turned a converged
+            #  solve into INFEASIBLE: a result dict of this class carries it)
+            if isinstance(warm, dict) and "status_solver" in warm: prev_status = warm["status_solver"]
             ps = np.ascontiguousarray(np.asarray(prev_status).reshape(B), dtype=np.int32)
         if sticky is not None:
             assert sticky.dtype == np.int32 and sticky.shape == (B,) and sticky.flags["C_CONTIGUOUS"]
@@ -154,7 +160,8 @@ class Oracle:
                                  sticky.ctypes.data_as(ip) if sticky is not None else None)
         return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
                     kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int),
-                    n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9])
+                    n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9], g0=st[:, 10],
+                    n_fallback=st[:, 11].astype(int), n_shift=st[:, 12].astype(int), status_solver=st[:, 13].astype(int))
 
 
 class VpVehicle(C.Structure):

@@ -14,6 +14,7 @@
 #include "aux_kernels.h"
 #include "velocity.h"
 
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -49,6 +50,22 @@ static void default_options(ltompc_options* o) {  // = ltompc_default_options
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1, o->resto_rho = 1000.0;
+  o->resto_rho_max = 1e7, o->resto_rho_factor = 1e4, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+}
+// further options as key=value arguments (tests of the option paths)
+static bool set_option(ltompc_options* o, const char* arg) {
+  const char* eq = strchr(arg, '=');
+  if (!eq) return false;
+  const std::string key(arg, eq - arg);
+  const double v = atof(eq + 1);
+#define OPT_D(name) if (key == #name) { o->name = v; return true; }
+#define OPT_I(name) if (key == #name) { o->name = (int)v; return true; }
+  OPT_D(resto_rho) OPT_D(resto_rho_max) OPT_D(resto_rho_factor) OPT_D(mu_init_warm) OPT_D(tol) OPT_D(mu_init)
+  OPT_I(node0_check) OPT_I(warm_fallback_iter) OPT_I(resto_shift_retry) OPT_I(warm_shift) OPT_I(resto_sticky) OPT_I(max_iter)
+  OPT_I(warm_reset_on_fail) OPT_I(stall_iter)
+#undef OPT_D
+#undef OPT_I
+  return false;
 }
 static void build_bounds(const ltompc_params& p, Bounds& b) {  // = build_bounds (ltompc.hip)
   memset(&b, 0, sizeof b);
@@ -88,6 +105,8 @@ int main(int argc, char** argv) {
   memset(&K, 0, sizeof K);
   default_params(&K.p), default_options(&K.o);
   K.o.soft_rho = soft_rho;
+  for (int a = 2; a < argc; a++)
+    if (!set_option(&K.o, argv[a])) return fprintf(stderr, "harness: unknown option %s\n", argv[a]), 2;
   K.p.ell_penalty = ell[0], K.p.ell_rho = ell[1], K.p.ell_D_f = ell[2], K.p.ell_D_r = ell[3];
   build_bounds(K.p, K.bd);
   const int ni = K.bd.ni, Bp = (B + 63) / 64 * 64;
@@ -113,6 +132,12 @@ int main(int argc, char** argv) {
   W.x0 = poisoned(8 * bp), W.uprev = poisoned(2 * bp), W.st = poisoned((size_t)ST_NF * bp), W.filt = poisoned((size_t)2 * FILTER_MAX * bp);
   W.si = ipoisoned((size_t)SI_NF * bp, 0), W.active = ipoisoned(K.o.max_iter + 2, 0), W.ls_list = ipoisoned(bp, -1), W.ls_count = ipoisoned(4, 0);
   W.DBG = nullptr;
+  W.BK = poisoned(18 * n * bp);
+  {
+    int* orig = ipoisoned(bp, -1);
+    for (int b = 0; b < B; b++) orig[b] = b;
+    W.orig = orig;
+  }
   std::vector<int> act(Bp), nact(1, B);
   for (int b = 0; b < Bp; b++) act[b] = b;
   Launch la{act.data(), nact.data(), Bp, 0};
@@ -122,6 +147,10 @@ int main(int argc, char** argv) {
     const int cold = tick == 0;
     grid64(B, [&] { k_load_x0(W, x.data(), nullptr, K.o.resto_sticky, cold ? 0 : 1); });
     if (cold) grid64(B, [&] { k_zero_uprev(W); });
+    if (!cold && K.o.warm_shift) {
+      grid64((N + 1) * Bp, [&] { k_shift(W, 0); });
+      grid64((N + 1) * Bp, [&] { k_shift(W, 1); });
+    }
     grid64(N * Bp, [&] { k_init(&K, &W, cold); });
     memset(W.active, 0, sizeof(int) * (K.o.max_iter + 2)), W.ls_count[0] = W.ls_count[1] = 0;
     for (int it = 0;; it++) {
@@ -152,8 +181,9 @@ int main(int argc, char** argv) {
     grid64(B, [&] { k_store_u0(W, u0.data(), nullptr); });
     printf("tick %d\n", tick);
     for (int b = 0; b < B; b++)
-      printf("%d %d %d %.17g %.17g %.17g\n", b, W.si[(size_t)SI_STATUS * Bp + b], W.si[(size_t)SI_ITERS * Bp + b], u0[2 * b], u0[2 * b + 1],
-             W.st[(size_t)ST_E0 * Bp + b]);
+      printf("%d %d %d %.17g %.17g %.17g %d %d %d %.17g %.17g\n", b, W.si[(size_t)SI_STATUS * Bp + b], W.si[(size_t)SI_ITERS * Bp + b], u0[2 * b], u0[2 * b + 1],
+             W.st[(size_t)ST_E0 * Bp + b], W.si[(size_t)SI_NRESTO * Bp + b], W.si[(size_t)SI_NSHIFT * Bp + b], W.si[(size_t)SI_NFALLBACK * Bp + b],
+             W.st[(size_t)ST_VIOL * Bp + b], W.st[(size_t)ST_G0 * Bp + b]);
     // plant step (k_plant) to the next tick's states
     Consts Kc = K;
     grid64(B, [&] { k_plant(Kc, B, x.data(), u0.data(), K.o.t_step, 100, xn.data()); });

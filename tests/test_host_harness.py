@@ -27,7 +27,7 @@ def harness():
     return EXE
 
 
-def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2, ell=(0.0, 0.0, 0.0, 0.0)):
+def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2, ell=(0.0, 0.0, 0.0, 0.0), **options):
     prob = tmp_path / "problem.txt"
     tab = tables.packed()
     with open(prob, "w") as f:
@@ -35,7 +35,7 @@ def _run(exe, tmp_path, tables, x0, N, any_bounds=0, soft_rho=0.0, ticks=2, ell=
         np.savetxt(f, tab.ravel()[None], fmt="%.17g")
         np.savetxt(f, x0.ravel()[None], fmt="%.17g")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    out = subprocess.run([exe, str(prob)], capture_output=True, text=True, env=env, timeout=900)
+    out = subprocess.run([exe, str(prob)] + [f"{k}={v!r}" for k, v in options.items()], capture_output=True, text=True, env=env, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]   # a sanitizer report ends the process with a non-zero code
     assert "runtime error" not in out.stderr and "AddressSanitizer" not in out.stderr, out.stderr[-3000:]
     res, cur = [], None
