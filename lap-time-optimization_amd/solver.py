@@ -98,7 +98,11 @@ class BatchedMPC:
         check(lib().ltompc_get_counters(self._h, iptr(nr), iptr(nf)))
         nre, viol = np.empty(self.B, dtype=np.int32), np.empty(self.B)
         check(lib().ltompc_get_restoration(self._h, iptr(nre), dptr(viol)))
-        return dict(status=st, iters=it, kkt=kkt, obj=obj, mu=mu, n_reg=nr, n_lsfail=nf, n_resto=nre, viol=viol)
+        nsh, nfb, sst = (np.empty(self.B, dtype=np.int32) for _ in range(3))
+        g0, pen = np.empty(self.B), np.empty(self.B)
+        check(lib().ltompc_get_recovery(self._h, iptr(nsh), iptr(nfb), dptr(g0), iptr(sst), dptr(pen)))
+        return dict(status=st, iters=it, kkt=kkt, obj=obj, mu=mu, n_reg=nr, n_lsfail=nf, n_resto=nre, viol=viol,
+                    n_shift=nsh, n_fallback=nfb, g0=g0, status_solver=sst, penalty=pen)
 
     def plant_step(self, x, u, n_sub: int = 400):
         x, u = self._x(x), np.ascontiguousarray(np.asarray(u, float).reshape(self.B, NU))
