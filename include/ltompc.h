@@ -121,10 +121,19 @@ typedef struct ltompc_options {
    * entry of the phase) and the elastic problem is solved again, until all elastic variables are <= tol (back to the hard
    * constraints, status SOLVED) or the penalty has reached resto_rho_max: only then the status is INFEASIBLE, a stationary
    * point of  objective / resto_rho_max + violation,  i.e. of the constraint violation itself up to 1 / resto_rho_max (IPOPT's
-   * restoration phase minimises the violation alone).  resto_rho_factor <= 1 or resto_rho_max <= resto_rho: no escalation,
+   * restoration phase minimises the violation alone; at 1e7 the escalated problems sit at the rounding floor and take 2 - 4
+   * times the iterations, at 1e6 the least violation is reproduced to 2 % down to violations of 1e-5 m).  resto_rho_factor <= 1 or resto_rho_max <= resto_rho: no escalation,
    * INFEASIBLE means "at penalty resto_rho" (round 2's behaviour). */
-  double resto_rho_max;    /* 1e7 */
-  double resto_rho_factor; /* 1e4 (one step to resto_rho_max) */
+  double resto_rho_max;    /* 1e6 */
+  double resto_rho_factor; /* 1e3 (one step to resto_rho_max) */
+  /* Early entry into the recovery steps (shifted restart, restoration phase): on the hard constraints, an iterate whose dual
+   * infeasibility (max-norm of the Lagrangian's gradient, unscaled) exceeds this.  On this NLP a solve that converges stays
+   * below 1e3 .. 1e4 after a warm start; the solves that exceed it are the ones whose multipliers diverge (1e5 -> 1e18) while
+   * the filter keeps accepting steps of a percent - 100 to 250 iterations until the line search finally fails, the slowest
+   * instances of every tick.  IPOPT has no such test (it would iterate on); it only changes WHEN the recovery starts, not
+   * what the solve returns when it converges.  Warm-started solves only (from do_mpc's cold start, every node = x0, a
+   * converging solve passes through dual infeasibilities of 1e7).  0 = off. */
+  double dual_inf_max;     /* 1e4 */
   int max_iter;           /* controller.py:18 says 1000.  Per instance: iterations plus repeated Riccati sweeps (inertia correction) */
   int acceptable_iter;    /* ipopt acceptable_iter      15   */
   int n_linesearch;       /* step-size candidates alpha_max * 2^-l, l = 0..n_linesearch-1 */
@@ -171,6 +180,11 @@ typedef struct ltompc_options {
                              many of these solves: from the shifted point they converge in ~15 iterations where the elastic
                              problem started at the jam point drifts into a local minimum of the violation.
                              0: straight to the restoration phase (round 2).  Ignored with warm_shift = 1.            (1) */
+  int max_mu_stay;        /* warm-started solves: after this many iterations without a decrease of the barrier parameter the
+                             iterates are wandering or cycling (the filter holds 16 pairs and forgets the oldest; a solve that
+                             converges needs ~60 at most on this NLP; one cycling instance running to max_iter = 1000 costs a
+                             tick of 8192 instances 200 ms).  On the hard constraints the recovery steps take over (shifted
+                             restart, restoration phase), elsewhere the solve ends with status STALLED.  0 = off.        (100) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),

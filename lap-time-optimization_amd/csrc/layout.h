@@ -80,6 +80,8 @@ enum : int { SI_STATUS = 0, SI_ITERS, SI_NACC, SI_NTINY, SI_NFILT, SI_DONE, SI_S
              SI_SINCEMU,  // options.warm_fallback_iter: iterations since the barrier parameter last decreased
              SI_FBARMED,  // ... the fallback is still available to this solve (it started at mu_init_warm)
              SI_NFALLBACK,
+             SI_BLOWUP,   // options.dual_inf_max: the head found the dual infeasibility beyond the limit; d_pick of this iteration sends
+                          // the solve to its recovery steps instead of taking the step
              SI_NODE0,    // options.node0_check turned the solver's status (value - 1: SOLVED / ACCEPTABLE) into INFEASIBLE: the next
                           // solve is warm-started as after a converged one
              SI_NF };  // SI_PREV: status of the previous make_step (k_load_x0)

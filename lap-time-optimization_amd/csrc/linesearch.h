@@ -286,7 +286,7 @@ __device__ __forceinline__ void d_pick(const Consts& K, const Work& W, const int
     STD(ST_FORCE_REG) = 0.0;
     int nt = alpha <= 1e-3 ? STI(SI_NTINY) + 1 : 0;
     STI(SI_NTINY) = nt;
-    if (o.stall_iter > 0 && nt >= o.stall_iter) {
+    if ((o.stall_iter > 0 && nt >= o.stall_iter) || (resto_ready && STI(SI_BLOWUP))) {  // (SI_BLOWUP: options.dual_inf_max, set by the head)
       if (resto_ready) enter_resto = true;
       else STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
       take = false;

@@ -273,7 +273,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
-  o->resto_rho_max = 1e7, o->resto_rho_factor = 1e4, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,
@@ -292,6 +292,8 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   if (options->resto_sticky < 0) return fail("ltompc_create: resto_sticky must be >= 0");
   if (!std::isfinite(options->resto_rho_max) || !std::isfinite(options->resto_rho_factor) || options->resto_rho_factor < 0)
     return fail("ltompc_create: resto_rho_max and resto_rho_factor must be finite, resto_rho_factor >= 0 (<= 1: no penalty escalation)");
+  if (!(options->dual_inf_max >= 0)) return fail("ltompc_create: dual_inf_max must be >= 0 (0 = off)");
+  if (options->max_mu_stay < 0) return fail("ltompc_create: max_mu_stay must be >= 0 (0 = off)");
   if (options->warm_fallback_iter < 0) return fail("ltompc_create: warm_fallback_iter must be >= 0 (0 = off)");
   if (options->max_soc != 0) return fail("ltompc_create: max_soc must be 0 (the second-order correction exists in the oracle only, see include/ltompc.h)");
   for (int r = 0; r < LTOMPC_TABLE_ROWS; r++)

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     if (E0 <= o.acceptable_tol) {
       int na = STI(SI_NACC) + 1;
       STI(SI_NACC) = na;
-      if (na >= o.acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE;
+      if (na >= o.acceptable_iter || (STI(SI_RESTO) == 1 && S > 1.0)) term = LTOMPC_STATUS_ACCEPTABLE;  // (escalated elastic problem: see d_head8)
     } else STI(SI_NACC) = 0;
     if (term < 0 && (iters >= o.max_iter || passes >= o.max_iter)) term = LTOMPC_STATUS_MAX_ITER;
   }
@@ -125,6 +125,8 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
     return;
   }
   if (it_index >= 0) atomicAdd(&W.active[it_index], 1);
+  const bool recoverable = rho == 0.0 && STI(SI_RESTO) == 0 && o.resto_rho > 0.0;  // on the hard constraints, recovery steps still ahead
+  STI(SI_BLOWUP) = (o.dual_inf_max > 0.0 && STI(SI_WARM) && recoverable && rd > o.dual_inf_max) ? 1 : 0;  // see d_head8
   // ---- monotone barrier update (IPOPT eq. (7)), in the units of the penalty scale ----
   bool mu_changed = false;
   {
@@ -145,6 +147,13 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   {  // options.warm_fallback_iter, see d_head8
     const int since = mu_changed ? 0 : STI(SI_SINCEMU) + 1;
     STI(SI_SINCEMU) = since;
+    if (STI(SI_WARM) && o.max_mu_stay > 0 && since >= o.max_mu_stay) {  // options.max_mu_stay, see d_head8
+      if (!recoverable) {
+        STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+        return;
+      }
+      STI(SI_BLOWUP) = 1;
+    }
     if (STI(SI_FBARMED) && since >= o.warm_fallback_iter) {
       STI(SI_FBARMED) = 0, STI(SI_NFALLBACK) += 1;
       restart_from_primal(K, W, b, rho);
@@ -424,7 +433,10 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     else {
       int na = (E0 <= o.acceptable_tol) ? STI(SI_NACC) + 1 : 0;
       if (i == 0) STI(SI_NACC) = na;
-      if (na >= o.acceptable_iter && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
+      // (an escalated elastic problem only has to answer "is some elastic variable > 0 at the least violation": the acceptable
+      //  level decides that at once - IPOPT's restoration phase does not iterate to the NLP's tolerance either; at S = 1e4 the
+      //  unscaled dual residual sits at the rounding floor, 1e-4 on multipliers of 1e7, i.e. 1e-8 scaled)
+      if ((na >= o.acceptable_iter || (STI(SI_RESTO) == 1 && S > 1.0)) && E0 <= o.acceptable_tol) term = LTOMPC_STATUS_ACCEPTABLE;
       if (term < 0 && (iters >= o.max_iter || passes >= o.max_iter)) term = LTOMPC_STATUS_MAX_ITER;
     }
     if (STI(SI_RESTO) == 1 && (term == LTOMPC_STATUS_SOLVED || term == LTOMPC_STATUS_ACCEPTABLE)) {
@@ -486,9 +498,20 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     // not decreased it for that many iterations is cycling around a point that is not central; once per solve it starts again
     // from its current primal point the way a solve after a failed one starts (multipliers 0, barrier at mu_init)
     const int since = mu_changed ? 0 : STI(SI_SINCEMU) + 1;
-    fallback = STI(SI_FBARMED) && since >= o.warm_fallback_iter;
+    const bool warm = STI(SI_WARM) != 0;
+    const bool recoverable = rho == 0.0 && STI(SI_RESTO) == 0 && o.resto_rho > 0.0;  // on the hard constraints, recovery steps still ahead
+    // options.max_mu_stay (warm-started solves): this many iterations without a decrease of the barrier parameter - the iterates
+    // wander or cycle (the filter holds FILTER_MAX pairs and forgets the oldest).  On the hard constraints the recovery steps
+    // take over at the end of this iteration, elsewhere the solve ends STALLED.
+    const bool stuck = warm && o.max_mu_stay > 0 && since >= o.max_mu_stay;
+    fallback = !(stuck && !recoverable) && STI(SI_FBARMED) && since >= o.warm_fallback_iter;
     if (i == 0) {
       STI(SI_SINCEMU) = since;
+      if (stuck && !recoverable) STI(SI_STATUS) = LTOMPC_STATUS_STALLED, STI(SI_DONE) = 1;
+      // options.dual_inf_max: on the hard constraints of a warm-started solve, a dual infeasibility beyond any scale of the
+      // problem (the multipliers diverge while the line search keeps accepting steps of a percent) sends the solve to its
+      // recovery steps at the end of this iteration (d_pick) instead of 100+ iterations later
+      STI(SI_BLOWUP) = (recoverable && (stuck || (o.dual_inf_max > 0.0 && warm && rd > o.dual_inf_max))) ? 1 : 0;
       if (mu_changed) {
         STD(ST_MU) = mu;
         STD(ST_EPS_NEXT) = (o.smooth_scale > 0 || o.smooth_eps_min > 0) ? fmax(o.smooth_eps_min, o.smooth_scale * (mu * iS)) : 0.0;
@@ -500,7 +523,7 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
         restart_from_primal(K, W, b, rho);
       }
     }
-    if (fallback) live = false;
+    if (fallback || (stuck && !recoverable)) live = false;
   }
   return __any(live);
 }

@@ -680,9 +680,12 @@ typedef struct {
   int n_reg, n_lsfail, n_soc, n_resto, n_fallback, n_shift;
   double viol; /* largest elastic variable at termination (0 on the hard constraints); g0 when node 0 decided the status */
   double g0;   /* largest track constraint at the measured state (options.node0_check) */
+  int trig; /* diagnostics (experiment): bit 0 / 1: the early-stall rule fired before / after the shifted restart */
+  int mu_stay_max; /* diagnostics: longest run of iterations without a decrease of the barrier parameter */
+  double rd_max; /* diagnostics: largest dual infeasibility (in the units of the penalty scale) any iterate of the solve had */
 } solve_stats;
 
-#define FILTER_MAX 64
+#define FILTER_MAX 16 /* (as on the device: the oldest pair leaves a full filter) */
 #define ELASTIC_CP_VIOL 0.1 /* [m] violation of a track constraint above which its elastic variable starts on the central path */
 #define DW_KEEP 1e-5
 #define RHO_UNIT 1000.0 /* penalty of the elastic variables at which the solve runs unscaled (IPOPT's restoration penalty), see S in solve_one */
@@ -1124,7 +1127,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   mu *= (o->soft_rho > RHO_UNIT ? o->soft_rho / RHO_UNIT : 1.0); /* (penalty scale S below: soft_rho > RHO_UNIT runs in scaled units) */
   s->mu = mu;
   init_slacks(s);
-  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0, st->n_fallback = 0, st->n_shift = 0;
+  st->n_reg = 0, st->n_lsfail = 0, st->n_soc = 0, st->n_resto = 0, st->n_fallback = 0, st->n_shift = 0, st->rd_max = 0.0, st->mu_stay_max = 0, st->trig = 0;
 
   /* filter */
   double filt_th[FILTER_MAX], filt_ph[FILTER_MAX];
@@ -1155,7 +1158,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   double eps_next = Tl.eps_s;
   int n_tiny = 0;
   /* options.warm_fallback_iter: iterations since the barrier parameter last decreased, in a solve that started at mu_init_warm */
-  int shift_retried = 0;
+  int shift_retried = 0, stuck = 0;
   int since_mu = 0, fallback_armed = (warm == 1 && o->mu_init_warm > 0 && o->warm_fallback_iter > 0);
   for (iter = 0;; iter++) {
     /* table smoothing follows the barrier parameter with a lag of one iteration (so that one linearisation
@@ -1212,6 +1215,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           }
         }
     }
+    if (rd / S > st->rd_max) st->rd_max = rd / S;
     double s_d = fmax(o->s_max, sum_mult / S / n_mult) / o->s_max;
     E0 = fmax(fmax(rd / S / s_d, rp), rc_0 / S / s_d);
     double Emu = fmax(fmax(rd / S / s_d, rp), rc_mu / S / s_d);
@@ -1219,7 +1223,10 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     if (!isfinite(E0)) term = LTOMPC_STATUS_NUMERICAL;
     else if (E0 <= o->tol) term = LTOMPC_STATUS_SOLVED;
     else {
-      if (E0 <= o->acceptable_tol) { if (++n_acc >= o->acceptable_iter) term = LTOMPC_STATUS_ACCEPTABLE; }
+      /* (an escalated elastic problem only has to answer "is some elastic variable > 0 at the least violation": the
+       *  acceptable level decides that at once, as IPOPT's restoration phase does not iterate to the NLP's tolerance either; at
+       *  S = 1e4 the unscaled dual residual sits at the rounding floor, 1e-4 on multipliers of 1e7, i.e. 1e-8 scaled) */
+      if (E0 <= o->acceptable_tol) { if (++n_acc >= o->acceptable_iter || (resto == 1 && S > 1.0)) term = LTOMPC_STATUS_ACCEPTABLE; }
       else n_acc = 0;
       if (term < 0 && iter >= o->max_iter) term = LTOMPC_STATUS_MAX_ITER;
     }
@@ -1250,7 +1257,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         mu = s->mu = o->mu_init * S;
         Tl.eps_s = eps_next = SMOOTHING(mu / S);
         init_slacks(s);
-        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0, since_mu = 0;
         st->n_resto++;
         iter--; /* (this pass only changed the problem: not an iteration) */
         continue;
@@ -1276,6 +1283,12 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     }
     s->mu = mu;
     since_mu = mu_changed ? 0 : since_mu + 1;
+    if (since_mu > st->mu_stay_max) st->mu_stay_max = since_mu;
+    /* options.max_mu_stay (warm-started solves): this many iterations without a decrease of the barrier parameter - the iterates
+     * wander or cycle (the filter holds FILTER_MAX pairs; a solve that converges needs at most ~60 on this NLP).  On the hard
+     * constraints the recovery steps take over at the end of this iteration, elsewhere the solve ends STALLED. */
+    stuck = warm && o->max_mu_stay > 0 && since_mu >= o->max_mu_stay;
+    if (stuck && !(resto_allowed && resto == 0)) { status = LTOMPC_STATUS_STALLED; break; }
     if (fallback_armed && since_mu >= o->warm_fallback_iter) {
       /* the solve started at the small barrier parameter of a tuned warm start and is going nowhere: once, start again
        * from the current primal point the way a solve after a failed one starts (multipliers 0, barrier at mu_init) */
@@ -1480,7 +1493,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
           mu = s->mu = o->mu_init;
           Tl.eps_s = eps_next = SMOOTHING(mu);
           init_slacks(s);
-          nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+          nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0, since_mu = 0;
           if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d -> start again from the shifted warm start\n", iter);
           continue;
         }
@@ -1496,7 +1509,7 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
         mu = s->mu = o->mu_init * S;
         Tl.eps_s = eps_next = SMOOTHING(mu / S);
         init_slacks(s);
-        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0;
+        nfilt = 0, theta0 = -1, delta_w_last = 0.0, force_reg = 0.0, n_tiny = 0, n_acc = 0, since_mu = 0;
         if (getenv("ORACLE_TRACE")) fprintf(stderr, "it %3d -> restoration (elastic mode, rho %.0f)\n", iter, o->resto_rho);
         continue;
       }
@@ -1510,14 +1523,21 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
     force_reg = 0.0;
     /* consecutive tiny steps: IPOPT would enter restoration */
     n_tiny = alpha <= 1e-3 ? n_tiny + 1 : 0;
+    /* options.dual_inf_max: on the hard constraints a dual infeasibility that has grown beyond any scale of the problem (the
+     * multipliers diverge while the line search keeps accepting steps of a percent: 100+ iterations before it finally fails)
+     * is treated like that failure at once: shifted restart, then the restoration phase.  Warm-started solves only: from do_mpc's
+     * cold start (every node = x0) a converging solve passes through dual infeasibilities of 1e7. */
+    const int blowup = stuck || (o->dual_inf_max > 0 && warm && resto_allowed && resto == 0 && rd > o->dual_inf_max);
+    if (blowup) st->trig |= (shift_retried ? 2 : 1);
+    if (blowup) goto enter_resto;
     if (o->stall_iter > 0 && n_tiny >= o->stall_iter) {
       if (resto_allowed && resto == 0) goto enter_resto;
       status = LTOMPC_STATUS_STALLED;
       break;
     }
     if (getenv("ORACLE_TRACE"))
-      fprintf(stderr, "it %3d mu %.2e E0 %.3e rd %.2e rp %.2e rc %.2e th0 %.3e ph0 %.6e a_pri %.3f a_dua %.3f alpha %.4f dw %.1e gphid %.3e acc %d obj %.6f u0 %.8f %.8f rdk %d rdv %d mu_k %.3e s_k %.4f\n",
-              iter, mu, E0, rd, rp, rc_0, th0, ph0, a_pri, a_dua, alpha, delta_w, gphi_d, accepted, obj, it->u[0], it->u[1], rd_k, rd_v, rd_k >= 0 ? it->x[(rd_k + 1) * NX + 2] : 0.0, rd_k >= 0 ? it->x[(rd_k + 1) * NX] : 0.0);
+      fprintf(stderr, "it %3d mu %.2e E0 %.3e rd %.2e rp %.2e rc %.2e th0 %.3e ph0 %.6e a_pri %.3f a_dua %.3f alpha %.4f dw %.1e gphid %.3e acc %d obj %.6f u0 %.8f %.8f rdk %d rdv %d mu_k %.3e s_k %.4f nfilt %d thmin %.2e\n",
+              iter, mu, E0, rd, rp, rc_0, th0, ph0, a_pri, a_dua, alpha, delta_w, gphi_d, accepted, obj, it->u[0], it->u[1], rd_k, rd_v, rd_k >= 0 ? it->x[(rd_k + 1) * NX + 2] : 0.0, rd_k >= 0 ? it->x[(rd_k + 1) * NX] : 0.0, nfilt, theta_min);
     /* ---- take the step ---- */
     for (int k = 1; k <= N; k++)
       for (int i = 0; i < NX; i++) it->x[k * NX + i] += alpha * dx[k * NX + i];
@@ -1599,7 +1619,8 @@ void oracle_default_options(ltompc_options* o) {
   o->kappa_eps = 10, o->kappa_mu = 0.2, o->theta_mu = 1.5, o->tau_min = 0.99, o->bound_push = 1e-2;
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
-  o->resto_rho_max = 1e7, o->resto_rho_factor = 1e4, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+  o->dual_inf_max = 1e4, o->max_mu_stay = 100;
   o->warm_reset_on_fail = 1; /* applied by the caller (oracle.py solve(prev_status=...)): this file sees one solve at a time */
 }
 
@@ -1707,7 +1728,7 @@ int oracle_plant_step(const ltompc_params* p, const double* tab, int nt, const d
 
 /* Batched solve.  Arrays are batch-major: X: B x (N+1) x 8, C: B x N x 8, U: B x N x 2, L1/L2: B x N x 8
  * (in: warm start if warm != 0; out: solution).  stats: B x 5 doubles (status, iters, kkt, obj, mu) +
- * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol + g0 + n_fallback + n_shift + status_solver => 14 doubles per instance. */
+ * 4 ints packed as doubles (n_reg, n_lsfail, n_soc, n_resto) + viol + g0 + n_fallback + n_shift + status_solver + rd_max + mu_stay_max => 16 doubles per instance. */
 int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const double* tab, int nt, int N, int B,
                        const double* x0, const double* uprev, int warm, double* X, double* C, double* U,
                        double* L1, double* L2, double* u0, double* stats, int nthreads, double* Tout, double* NUout,
@@ -1745,9 +1766,9 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
       else if (sticky[b] > 0) sticky[b]--;
     }
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
-    double* s = stats + (size_t)b * 14;
+    double* s = stats + (size_t)b * 17;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;
-    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol, s[10] = st.g0, s[11] = st.n_fallback, s[12] = st.n_shift, s[13] = st.status_solver;
+    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol, s[10] = st.g0, s[11] = st.n_fallback, s[12] = st.n_shift, s[13] = st.status_solver, s[14] = st.rd_max, s[15] = st.mu_stay_max, s[16] = st.trig;
   }
   return 0;
 }
