@@ -308,13 +308,17 @@ int ltompc_get_launch_log(ltompc_handle h, int* kind, int* width, double* ms, in
 int ltompc_get_launch_log_iterations(ltompc_handle h, int* iteration, int capacity);
 
 /* Number of unfinished instances after every iteration of the last make_step (entry i: instances that passed the
- * termination test of iteration i and went on); returns the number of iterations launched. */
+ * termination test of iteration i and went on); returns the number of iterations launched (0 after a rollout, which keeps
+ * no per-iteration counts). */
 int ltompc_get_active_history(ltompc_handle h, int* active, int capacity);
 
 /* Histogram of the per-instance statuses of the last solve (counts8[s], s = LTOMPC_STATUS_*; entry 7 collects anything
  * else) and the sum of the instances' iteration counts, reduced on the device: cheaper than ltompc_get_stats and does
  * not disturb the packed order of the instances.  Either output may be NULL. */
 int ltompc_get_status_counts(ltompc_handle h, int* counts8, long long* iterations_sum);
+/* ... and the histogram of the solver's own statuses (before the node-0 rule of options.node0_check) that the last
+ * ltompc_get_status_counts call reduced along with it. */
+int ltompc_get_solver_status_counts(ltompc_handle h, int* counts8);
 
 /* Poll history of the last make_step: up to `capacity` triples (iteration, unfinished instances, launch width);
  * returns the number of polls (>= 0). */

@@ -269,6 +269,9 @@ __global__ void k_status_counts(Work W, int* __restrict__ counts, unsigned long 
   if (b >= W.B) return;
   const int s = W.si[(size_t)SI_STATUS * W.Bp + b];
   atomicAdd(&counts[s < 0 ? 7 : (s > 7 ? 7 : s)], 1);
+  // counts[16 .. 23]: the solver's own statuses (before the node-0 rule of options.node0_check)
+  const int n0 = W.si[(size_t)SI_NODE0 * W.Bp + b], ss = n0 ? n0 - 1 : s;
+  atomicAdd(&counts[16 + (ss < 0 ? 7 : (ss > 7 ? 7 : ss))], 1);
   atomicAdd(iters_sum, (unsigned long long)W.si[(size_t)SI_ITERS * W.Bp + b]);
 }
 

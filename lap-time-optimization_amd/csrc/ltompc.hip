@@ -53,6 +53,7 @@ struct ltompc_solver {
   bool packing = true;  // LTOMPC_PACK=0: re-pack the list of unfinished instances only, leave their data where it is
   std::vector<int> history;  // (iteration, n_active, n_launch) triples of the last make_step's polls
   bool cold_next = true;
+  bool after_rollout = false;  // the last solve was a rollout: W.active holds no per-iteration counts
   int poll_every = 4;
   int profiling = 0;  // 0 off, 1 every launch bracketed, 2 + c: launches of kernel class c only
   bool compaction = true;       // LTOMPC_COMPACT=0 switches the re-packing of unfinished instances off
@@ -66,7 +67,8 @@ struct ltompc_solver {
   std::vector<double> log_ms;
   int cur_width = 0;  // instances in the launches being issued
   int cur_iter = 0;   // interior-point iteration the launches being issued belong to
-  int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum (k_status_counts)
+  int* d_counts = nullptr;  // 8 status counters + 1 x 64-bit iteration sum + 8 solver-status counters (k_status_counts)
+  int solver_counts[8] = {};  // ... the last ones read (ltompc_get_solver_status_counts)
   // rollout: per pass (ring slot) the number of instances that still have ticks to do and the list of the instances that
   // converged in it; their plant steps run beside the solver, on two low-priority streams in turn (a plant kernel takes 1 - 2 ms,
   // longer than a pass: one stream cannot keep up, 1870 ms instead of 1170 ms for 20 ticks; four are slower than two)
@@ -389,7 +391,7 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
   rc |= h->dalloc(&W.ls_list, Bp), rc |= h->dalloc(&W.ls_count, 4);
   rc |= h->dalloc(&h->d_perm, Bp), rc |= h->dalloc(&h->d_orig, Bp);
   rc |= h->dalloc(&W.BK, 18 * N * Bp, true);  // starting point of the current solve (options.resto_shift_retry)
-  rc |= h->dalloc(&h->d_counts, 16), rc |= h->dalloc(&h->d_roll, 2 * ltompc_solver::ROLL_RING);
+  rc |= h->dalloc(&h->d_counts, 32), rc |= h->dalloc(&h->d_roll, 2 * ltompc_solver::ROLL_RING);
   rc |= h->dalloc(&h->d_plist, (size_t)ltompc_solver::ROLL_RING * h->Bp);
   if (getenv("LTOMPC_DBG")) rc |= h->dalloc(&W.DBG, 8 * N * Bp);
   rc |= h->dalloc(&h->d_x0_rm, 8 * Bp), rc |= h->dalloc(&h->d_u0_rm, 2 * Bp), rc |= h->dalloc(&h->d_io, 32 * Bp);
@@ -506,7 +508,7 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   hipLaunchKernelGGL(k_init, dim3((N * Bp + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, h->cold_next ? 1 : 0);
   HIPCHECK(hipMemsetAsync(h->W.active, 0, sizeof(int) * ((size_t)h->max_iter + 2), h->stream));
   HIPCHECK(hipMemsetAsync(h->W.ls_count, 0, 2 * sizeof(int), h->stream));
-  h->cold_next = false;
+  h->cold_next = false, h->after_rollout = false;
   // all instances unfinished: identity list
   int cur = 0, n_launch = B;
   hipLaunchKernelGGL(k_act_identity, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->d_act[0], h->d_nact[0], B);
@@ -630,7 +632,8 @@ int ltompc_get_restoration(ltompc_handle h, int* n_resto, double* violation) {
     if (n_resto) n_resto[b] = si[(size_t)SI_NRESTO * h->Bp + b];
     // (meaningful while the elastic variables exist: 0 once the solve is back on the hard constraints; g(x0) when the
     //  node-0 rule decided the status)
-    if (violation) violation[b] = (st[(size_t)ST_RHO * h->Bp + b] > 0.0 || si[(size_t)SI_NODE0 * h->Bp + b]) ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
+    const bool node0_inf = si[(size_t)SI_NODE0 * h->Bp + b] && si[(size_t)SI_STATUS * h->Bp + b] == LTOMPC_STATUS_INFEASIBLE;
+    if (violation) violation[b] = (st[(size_t)ST_RHO * h->Bp + b] > 0.0 || node0_inf) ? st[(size_t)ST_VIOL * h->Bp + b] : 0.0;
   }
   return 0;
 }
@@ -700,17 +703,24 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
   long long it = 0;
   bool first = true;
   int rc = 0;
+  // (inside the loop a HIP error leaves through ONE exit: the plant streams and the solver stream are drained and the handle's
+  //  profiling mode restored before the call returns - plant kernels may still be writing x_dev and the lists otherwise)
+#define ROLLCHECK(expr)                                                                          \
+  {                                                                                              \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) { rc = fail(std::string(#expr) + ": " + hipGetErrorString(e_)); break; } \
+  }
   for (;; it++) {
     const int np = la.n_pad, slot = (int)(it % RING);
     int* const d_cnt = h->d_roll + 2 * slot;
     int* const d_list = h->d_plist + (size_t)slot * Bp;
-    if (done_pending[slot]) HIPCHECK(hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));  // (the plant kernel that read this slot's list, RING passes ago)
-    HIPCHECK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), h->stream));
+    if (done_pending[slot]) ROLLCHECK(hipStreamWaitEvent(h->stream, h->ev_done[slot], 0));  // (the plant kernel that read this slot's list, RING passes ago)
+    ROLLCHECK(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), h->stream));
     hipLaunchKernelGGL(k_roll_mark, dim3((B + 63) / 64), dim3(64), 0, h->stream, h->W, (const double*)x_dev, h->K.o.resto_sticky,
                        (first && h->cold_next) ? 1 : 0);  // (after set_initial_guess there is no solve before this one to take stock of)
     hipLaunchKernelGGL(k_roll_init, dim3((N * np + 63) / 64), dim3(64), 0, h->stream, h->d_K, h->d_W, la, (first && h->cold_next) ? 1 : 0);
     la.force_eval = 0;
-    if (launch_iteration(h, L, la, (int)(it % ring), n_launch, ls_width, ell, false) < 0) { rc = -1; break; }
+    if (launch_iteration(h, L, la, -1, n_launch, ls_width, ell, false) < 0) { rc = -1; break; }  // (-1: no per-iteration count of unfinished instances, a make_step facility)
     hipLaunchKernelGGL(k_roll_finish, dim3((np + 63) / 64), dim3(64), 0, h->stream, h->W, la, u_log_dev, status_log_dev, iters_log_dev, n_ticks,
                        d_cnt, d_list);
     // The plant steps of the instances that have just converged (the list k_roll_finish made: a plant step is ~1 ms of one
@@ -721,18 +731,18 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
     // pass, and the solver stream then waits 0.5 ms per pass (scratch/rtrace.sh).
     {
       hipStream_t ps = h->plant_streams[it % h->n_plant_streams];
-      HIPCHECK(hipEventRecord(h->ev_fin[slot], h->stream));
-      HIPCHECK(hipStreamWaitEvent(ps, h->ev_fin[slot], 0));
+      ROLLCHECK(hipEventRecord(h->ev_fin[slot], h->stream));
+      ROLLCHECK(hipStreamWaitEvent(ps, h->ev_fin[slot], 0));
       hipLaunchKernelGGL(k_roll_plant, dim3((n_launch + 63) / 64), dim3(64), 0, ps, h->K, h->W, x_dev, h->K.o.t_step, n_sub, (const int*)(d_cnt + 1),
                          (const int*)d_list);
-      HIPCHECK(hipEventRecord(h->ev_done[slot], ps));
+      ROLLCHECK(hipEventRecord(h->ev_done[slot], ps));
       done_pending[slot] = true;
     }
     first = false;
     if ((it + 1) % h->poll_every == 0) {
-      HIPCHECK(hipMemcpyAsync(h->h_active, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIPCHECK(hipStreamSynchronize(h->stream));
+      ROLLCHECK(hipMemcpyAsync(h->h_active, d_cnt, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      ROLLCHECK(hipMemcpyAsync(h->h_active + 1, h->W.ls_count + 1, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      ROLLCHECK(hipStreamSynchronize(h->stream));
       const int n_left = h->h_active[0];  // instances that still have ticks to do (counted before this iteration's plant steps)
       h->history.push_back((int)it), h->history.push_back(n_left), h->history.push_back(n_launch);
       if (h->ls_width_env == 0) {
@@ -751,13 +761,17 @@ int ltompc_rollout_dev(ltompc_handle h, double* x_dev, int n_ticks, int n_sub, d
       }
     }
   }
-  for (int i = 0; i < h->n_plant_streams; i++) HIPCHECK(hipStreamSynchronize(h->plant_streams[i]));
-  HIPCHECK(hipStreamSynchronize(h->stream));
-  HIPCHECK(hipGetLastError());
+#undef ROLLCHECK
+  // the one exit: drain every stream the rollout used (also after an error), restore the handle's state
+  for (int i = 0; i < h->n_plant_streams; i++)
+    if (hipStreamSynchronize(h->plant_streams[i]) != hipSuccess && rc == 0) rc = fail("ltompc_rollout: plant stream failed");
+  if (hipStreamSynchronize(h->stream) != hipSuccess && rc == 0) rc = fail("ltompc_rollout: solver stream failed");
+  if (hipGetLastError() != hipSuccess && rc == 0) rc = fail("ltompc_rollout: a kernel launch failed");
   h->profiling = prof;
   h->cold_next = false;
   h->roll_iterations = it + 1, h->roll_launches = L.launches;
-  h->last_iterations = (int)std::min<long long>(it + 1, 1 << 30);
+  h->last_iterations = 0;  // (no per-iteration history after a rollout: ltompc_get_active_history returns 0)
+  h->after_rollout = true;
   return rc;
 }
 
@@ -879,8 +893,8 @@ int ltompc_get_launch_log_iterations(ltompc_handle h, int* iteration, int capaci
 int ltompc_get_active_history(ltompc_handle h, int* active, int capacity) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
-  const int n = std::min(h->last_iterations, h->max_iter + 2);
-  if (active && capacity > 0) {
+  const int n = h->after_rollout ? 0 : std::min(h->last_iterations, h->max_iter + 2);
+  if (active && capacity > 0 && n > 0) {
     HIPCHECK(hipMemcpyAsync(active, h->W.active, sizeof(int) * std::min(n, capacity), hipMemcpyDeviceToHost, h->stream));
     HIPCHECK(hipStreamSynchronize(h->stream));
   }
@@ -890,16 +904,24 @@ int ltompc_get_active_history(ltompc_handle h, int* active, int capacity) {
 int ltompc_get_status_counts(ltompc_handle h, int* counts8, long long* iterations_sum) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));
-  HIPCHECK(hipMemsetAsync(h->d_counts, 0, sizeof(int) * 16, h->stream));
+  HIPCHECK(hipMemsetAsync(h->d_counts, 0, sizeof(int) * 32, h->stream));
   hipLaunchKernelGGL(k_status_counts, dim3((h->B + 255) / 256), dim3(256), 0, h->stream, h->W, h->d_counts,
                      reinterpret_cast<unsigned long long*>(h->d_counts + 8));
   HIPCHECK(hipGetLastError());
-  int host[16];
+  int host[32];
   HIPCHECK(hipMemcpyAsync(host, h->d_counts, sizeof host, hipMemcpyDeviceToHost, h->stream));
   HIPCHECK(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < 8; i++)
+  for (int i = 0; i < 8; i++) {
     if (counts8) counts8[i] = host[i];
+    h->solver_counts[i] = host[16 + i];
+  }
   if (iterations_sum) std::memcpy(iterations_sum, host + 8, sizeof(long long));
+  return 0;
+}
+
+int ltompc_get_solver_status_counts(ltompc_handle h, int* counts8) {
+  if (!h || !counts8) return fail("ltompc_get_solver_status_counts: null argument");
+  for (int i = 0; i < 8; i++) counts8[i] = h->solver_counts[i];
   return 0;
 }
 

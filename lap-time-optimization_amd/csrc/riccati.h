@@ -19,7 +19,11 @@ __device__ __forceinline__ int node0_rule(const ltompc_options& o, const double 
     node0 = term + 1;
     return LTOMPC_STATUS_INFEASIBLE;
   }
-  return g0 > o.tol ? LTOMPC_STATUS_ACCEPTABLE : term;
+  if (g0 > o.tol && term == LTOMPC_STATUS_SOLVED) {
+    node0 = term + 1;
+    return LTOMPC_STATUS_ACCEPTABLE;
+  }
+  return term;
 }
 // The solve of instance b starts again from its current primal point (the next evaluation kernel re-initialises the slots:
 // SI_REINIT): slacks / multipliers / elastic variables for penalty `rho`, equality multipliers 0, barrier at mu_init (in the
@@ -118,7 +122,8 @@ __global__ void __launch_bounds__(64) k_riccati(const Consts* __restrict__ Kp, c
   {
     int node0;
     term = node0_rule(o, STD(ST_G0), term, node0);
-    if (node0) STI(SI_NODE0) = node0, STD(ST_VIOL) = STD(ST_G0);
+    if (node0) STI(SI_NODE0) = node0;
+    if (node0 && term == LTOMPC_STATUS_INFEASIBLE) STD(ST_VIOL) = STD(ST_G0);
   }
   if (term >= 0) {
     STI(SI_STATUS) = term, STI(SI_DONE) = 1;
@@ -458,7 +463,7 @@ __device__ __forceinline__ bool d_head8(const Consts& K, const Work& W, const in
     int node0;
     term = node0_rule(o, STD(ST_G0), term, node0);
     if (i == 0) {
-      STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = node0 ? STD(ST_G0) : emax;
+      STD(ST_E0) = E0, STD(ST_OBJ) = obj, STD(ST_VIOL) = (node0 && term == LTOMPC_STATUS_INFEASIBLE) ? STD(ST_G0) : emax;
       if (node0) STI(SI_NODE0) = node0;
       if (term >= 0) STI(SI_STATUS) = term, STI(SI_DONE) = 1;
       if (to_hard) {

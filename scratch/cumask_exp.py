@@ -50,3 +50,8 @@ for name, (sa, sb) in (("no masks (two plain streams)", (None, None)), ("masks: 
     # small's ticks that overlapped with big's run
     print(f"   concurrent: big {np.mean(ta)*1e3:7.1f} ms per tick, small {np.mean(tb[:30])*1e3:6.2f} ms per tick (median {np.median(tb[:30])*1e3:.2f})", flush=True)
     big["m"].close(); small["m"].close()
+    # (the handles are closed first, then the streams they ran on are destroyed: round 2's runs of this script under rocprofv3
+    #  ended with a SIGSEGV in __cxa_finalize after the tool's finalisation - streams created here, in particular the CU-masked
+    #  ones, were still alive at interpreter exit)
+    torch.cuda.synchronize(dev)
+    assert hip.hipStreamDestroy(SA) == 0 and hip.hipStreamDestroy(SB) == 0

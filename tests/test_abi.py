@@ -43,6 +43,42 @@ def test_struct_layout_matches_c(pkg, tmp_path):
     assert C.sizeof(orc.Params) == sp and C.sizeof(orc.Options) == so
 
 
+def test_integration_md_binding_matches_the_header(pkg, tmp_path):
+    """INTEGRATION.md shows the ctypes binding a maintainer of the reference would add (its struct lists had gone
+    stale and following them overran the heap).  The two Structure definitions are taken out of the document, executed, and
+    compared with the compiled header: field names and order against the C declarations, sizes and the offset of the last
+    field against gcc's, and field for field against the package's own binding."""
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = md[md.index("class Params(C.Structure)"):md.index("STATUS = {")]
+    ns = {"C": C}
+    exec(code, ns)
+    P, O = ns["Params"], ns["Options"]
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    def c_fields(struct):
+        body = re.search(r"typedef struct " + struct + r" \{(.*?)\} " + struct + ";", hdr, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            m = re.match(r"\s*(double|int)\s+(.*)", decl.strip(), flags=re.S)
+            if m:
+                names += [re.sub(r"\[.*?\]", "", n).strip() for n in m.group(2).split(",")]
+        return names
+    assert [n for n, _ in P._fields_] == c_fields("ltompc_params")
+    assert [n for n, _ in O._fields_] == c_fields("ltompc_options")
+    src = tmp_path / "sz2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ltompc.h"\nint main(){printf("%zu %zu %zu %zu\\n", '
+                   'sizeof(ltompc_params), sizeof(ltompc_options), offsetof(ltompc_params, ell_D_r), offsetof(ltompc_options, latency_mode));return 0;}\n')
+    exe = tmp_path / "sz2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sp, so, o1, o2 = map(int, subprocess.check_output([str(exe)]).split())
+    assert (C.sizeof(P), C.sizeof(O), P.ell_D_r.offset, O.latency_mode.offset) == (sp, so, o1, o2)
+    L = importlib.import_module("lap-time-optimization_amd._lib")
+    assert [(n, C.sizeof(t)) for n, t in P._fields_] == [(n, C.sizeof(t)) for n, t in L.Params._fields_]
+    assert [(n, C.sizeof(t)) for n, t in O._fields_] == [(n, C.sizeof(t)) for n, t in L.Options._fields_]
+    # every status the header defines is known to the stub
+    assert sorted(eval(md[md.index("STATUS = {") + 9:md.index("}", md.index("STATUS = {")) + 1])) == sorted(
+        int(v) for v in re.findall(r"#define LTOMPC_STATUS_[A-Z_]+ (\d+)", open(HEADER).read()))
+
+
 def test_defaults_are_the_reference_values(pkg, gpu_lib, orc):
     p, o = pkg.default_params(), pkg.default_options()
     # data/vehicles/MX5.json through model.py:42-64 (D_f = D_r = 1.0: never read), controller.py:29,79-103, mpc.py:104
