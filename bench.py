@@ -9,13 +9,18 @@ One "step" = one control tick of the reference's closed loop (src/mpc.py:140-153
 make_step (one NLP solve per instance, warm-started from the previous solution, the reference's solver settings incl.
 max_iter = 1000) followed by the plant step that produces the next x0.  Inputs are resident in HBM when the timed region starts.
 Workload: BASELINE.json's metric config — horizon N = 40, 8192 instances per GPU sampled along buckmore (SURVEY.md §8d
-C3/C4), weak scaling (per-GPU batch fixed; instances are independent NLPs, no data-path collective).
+C3/C4), weak scaling (per-GPU batch fixed; instances are independent NLPs, no data-path collective): that is `value`.
+With N > 1 the same command ALSO measures BASELINE config 4 as stated, 8192 instances in TOTAL sharded over the N GPUs
+(`config4_total_8192`, strong scaling, 8192 / N per GPU), and every tick gathers the controls on all ranks over RCCL
+(`sharding.gather_rows`, the one collective north_star names; its cost is reported as `gather_ms`).  `--total-batch T` makes
+the strong-scaling shape the headline instead (`"scaling": "strong"`).
 `value` counts CONVERGED solves only (status SOLVED / ACCEPTABLE); `solves_attempted_per_s` has every instance.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import importlib
 import json
 import os
 import subprocess
@@ -95,6 +100,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
+    ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances in TOTAL, sharded over the GPUs in contiguous "
+                    "blocks (BASELINE config 4: 8192); 0 = weak scaling with --batch instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
     ap.add_argument("--max-iter", type=int, default=1000, help="interior-point iteration budget per solve (reference: ipopt.max_iter = 1000, controller.py:18)")
     ap.add_argument("--soft-rho", type=float, default=0.0, help="options.soft_rho for the timed run and the CPU baseline (extension: "
@@ -147,28 +154,43 @@ def stub_main(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    B = args.batch
-    for _ in range(args.warmup):
-        time.sleep(0.001)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    converged = 0
-    for _ in range(args.steps):
-        time.sleep(0.002 * (1 + rank))  # ranks differ: the slowest one sets the time
-        converged += B - rank  # rank r "fails" r instances per tick
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-    _, _, elapsed_max = shard.reduce_stats(0, 0, elapsed)
-    tot = torch.tensor([float(converged)], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    def shape(total):
+        """one timed region: total = 0 -> args.batch per rank (weak), else `total` instances sharded over the ranks (strong)"""
+        lo, hi = shard.shard_range(total, rank, world) if total else (rank * args.batch, (rank + 1) * args.batch)
+        Bl, n_all = hi - lo, (total if total else args.batch * world)
+        for _ in range(args.warmup):
+            time.sleep(0.001)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        converged, checksum = 0, 0.0
+        for k in range(args.steps):
+            time.sleep(0.002 * (1 + rank))  # ranks differ: the slowest one sets the time
+            converged += Bl - rank  # rank r "fails" r instances per tick
+            u = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1).repeat(1, 2) + k   # stand-in for the controls of the shard
+            g = shard.gather_rows(u, n_all, rank, world)  # the per-tick collective of the real run
+            assert g.shape == (n_all, 2) and float(g[-1, 0]) == n_all - 1 + k
+            checksum += float(g.sum())
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        _, _, elapsed_max = shard.reduce_stats(0, 0, elapsed)
+        tot = torch.tensor([float(converged)], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        return dict(value=float(tot.item()) / elapsed_max, ms_per_step=1e3 * elapsed_max / args.steps, converged_solves=float(tot.item()),
+                    batch_per_gpu=Bl, total_batch=n_all, gathered_checksum=checksum)
+    head = shape(args.total_batch)
+    extra = shape(8192) if (world > 1 and not args.total_batch) else None
     if rank == 0:
-        print(json.dumps({"metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": float(tot.item()) / elapsed_max, "unit": "MPC solves/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed_max / args.steps,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
-                          "config": {"workload": "plumbing self-test, no solver", "batch_per_gpu": B}, "converged_solves": float(tot.item())}))
+        out = {"metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": head["value"], "unit": "MPC solves/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+               "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None, "dtype": "f64", "data": "stub",
+               "config": {"workload": "plumbing self-test, no solver", "batch_per_gpu": head["batch_per_gpu"], "total_batch": head["total_batch"]},
+               "converged_solves": head["converged_solves"], "gathered_checksum": head["gathered_checksum"]}
+        if extra:
+            out["config4_total_8192"] = dict(extra, scaling="strong")
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
@@ -188,10 +210,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world}")
+    # Rehearsal of the N > 1 path on a box with ONE GPU (development only, never a measurement: the line says so):
+    # LTOMPC_BENCH_REHEARSAL=1 puts every rank on device 0 and uses gloo for the collectives (RCCL refuses two ranks on one device).
+    rehearsal = os.environ.get("LTOMPC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -199,7 +229,10 @@ def main():
 
     ltompc.build_library()
     tables = ltompc.build_tables()  # buckmore / MX-5 / curvature race line (the only one the reference MPC runs on)
-    B, N = args.batch, args.horizon
+    shard = importlib.import_module("lap-time-optimization_amd.sharding")
+    N = args.horizon
+    lo, hi = shard.shard_range(args.total_batch, rank, world) if args.total_batch else (rank * args.batch, (rank + 1) * args.batch)
+    B, n_total = hi - lo, (args.total_batch if args.total_batch else args.batch * world)
     opts = ltompc.default_options()
     opts.max_iter, opts.soft_rho, opts.resto_sticky = args.max_iter, args.soft_rho, args.resto_sticky
     mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
@@ -207,20 +240,32 @@ def main():
     mpc.set_stream(stream.cuda_stream)
     mpc.set_poll_every(args.poll_every)
 
-    x0_host = ltompc.sample_x0(tables, B, seed=ltompc.scenarios.SEED + rank)
-    x = torch.from_numpy(x0_host).to(dev)
+    # weak scaling: every rank samples its own 8192 states; strong scaling: ONE batch of n_total states, rank r holds rows [lo, hi)
+    x0_host = ltompc.sample_x0(tables, n_total, seed=ltompc.scenarios.SEED)[lo:hi] if args.total_batch else ltompc.sample_x0(tables, B, seed=ltompc.scenarios.SEED + rank)
+    x = torch.from_numpy(np.ascontiguousarray(x0_host)).to(dev)
     xn = torch.empty_like(x)
     u = torch.zeros(B, 2, dtype=torch.float64, device=dev)
 
-    def tick():
+    gather_ev = []  # (start, end) events around the gather of every timed tick
+
+    def tick(timed=False):
         nonlocal x, xn
         mpc.make_step_dev(x.data_ptr(), u.data_ptr())
         mpc.plant_step_dev(x.data_ptr(), u.data_ptr(), xn.data_ptr(), PLANT_SUBSTEPS)
         x, xn = xn, x
+        if world > 1:
+            # the controls of the whole batch on every rank (north_star: results gathered over RCCL / xGMI): one all_gather of
+            # 16 B per instance, on the stream the solver runs on; nothing in the next tick depends on it
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            shard.gather_rows(u, n_total, rank, world)
+            e1.record(stream)
+            if timed:
+                gather_ev.append((e0, e1))
 
     def barrier():
         if world > 1:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if rehearsal else dist.barrier(device_ids=[local_rank])
 
     # ---- warm-up: cold start (do_mpc set_initial_guess) + W ticks, untimed.  Every launch is bracketed by HIP events
     #      in the last of them: which kernel class takes the most device time (the one the roofline is quoted for; all 8
@@ -243,10 +288,12 @@ def main():
     barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
+    per_tick_solver = []
     for _ in range(args.steps):
-        tick()
+        tick(timed=True)
         c, isum = mpc.status_counts()
         per_tick_counts.append(c), per_tick_itersum.append(isum)
+        per_tick_solver.append(mpc.solver_status_counts())
         per_tick_iters.append(mpc.timing()["ip_iterations"])
         if not args.no_profile:
             active_hist.append(mpc.active_history())
@@ -259,19 +306,59 @@ def main():
     mpc.set_profiling(False)
 
     counts = np.array(per_tick_counts, dtype=np.float64)  # (K, 8)
+    scounts = np.array(per_tick_solver, dtype=np.float64)  # (K, 8): the solver's own statuses (before the node-0 rule)
     itersum = np.array(per_tick_itersum, dtype=np.float64)
+    gather_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_ev])) if gather_ev else 0.0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, gather_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        agg = torch.from_numpy(np.concatenate([counts.ravel(), itersum])).to(dev)
+        elapsed, gather_ms = float(t[0].item()), float(t[1].item())
+        agg = torch.from_numpy(np.concatenate([counts.ravel(), scounts.ravel(), itersum])).to(dev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         agg = agg.cpu().numpy()
-        counts, itersum = agg[:counts.size].reshape(counts.shape), agg[counts.size:]
-    n_all = B * world
+        counts, scounts, itersum = agg[:counts.size].reshape(counts.shape), agg[counts.size:2 * counts.size].reshape(counts.shape), agg[2 * counts.size:]
+    n_all = n_total
     converged_per_tick = counts[:, 0] + counts[:, 1]
     value = float(converged_per_tick.sum()) / elapsed
     attempted = n_all * args.steps / elapsed
+    solver_value = float((scounts[:, 0] + scounts[:, 1]).sum()) / elapsed
+
+    # ---- N > 1, weak-scaling headline: BASELINE config 4 as stated in the same run - 8192 instances in TOTAL over the N GPUs
+    config4 = None
+    if world > 1 and not args.total_batch:
+        T4 = 8192
+        l4, h4 = shard.shard_range(T4, rank, world)
+        m4 = ltompc.BatchedMPC(tables, n_horizon=N, batch=h4 - l4, options=opts, device=local_rank)
+        m4.set_stream(stream.cuda_stream)
+        m4.set_poll_every(args.poll_every)
+        x4 = torch.from_numpy(np.ascontiguousarray(ltompc.sample_x0(tables, T4, seed=ltompc.scenarios.SEED)[l4:h4])).to(dev)
+        x4n, u4 = torch.empty_like(x4), torch.zeros(h4 - l4, 2, dtype=torch.float64, device=dev)
+        m4.set_initial_guess_dev(x4.data_ptr())
+        ev4, c4 = [], []
+        for s4 in range(args.warmup + args.steps):
+            if s4 == args.warmup:
+                barrier(); torch.cuda.synchronize(dev)
+                t4 = time.perf_counter()
+            m4.make_step_dev(x4.data_ptr(), u4.data_ptr())
+            m4.plant_step_dev(x4.data_ptr(), u4.data_ptr(), x4n.data_ptr(), PLANT_SUBSTEPS)
+            x4, x4n = x4n, x4
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream); shard.gather_rows(u4, T4, rank, world); e1.record(stream)
+            if s4 >= args.warmup:
+                ev4.append((e0, e1))
+                c4.append(m4.status_counts()[0])
+        torch.cuda.synchronize(dev); barrier()
+        t4 = time.perf_counter() - t4
+        r4 = torch.tensor([t4, float(np.mean([a.elapsed_time(b) for a, b in ev4]))], dtype=torch.float64, device=dev)
+        dist.all_reduce(r4, op=dist.ReduceOp.MAX)
+        a4 = torch.from_numpy(np.array(c4, dtype=np.float64)).to(dev)
+        dist.all_reduce(a4, op=dist.ReduceOp.SUM)
+        a4 = a4.cpu().numpy()
+        config4 = {"workload": f"BASELINE config 4: batch={T4} in total, contiguous shards of {T4 // world} per GPU over {world} GPUs, horizon N={N}",
+                   "scaling": "strong", "value": float((a4[:, 0] + a4[:, 1]).sum()) / float(r4[0].item()), "unit": "MPC solves/s",
+                   "ms_per_step": 1e3 * float(r4[0].item()) / args.steps, "batch_per_gpu": h4 - l4, "total_batch": T4,
+                   "gather_ms": float(r4[1].item()), "solved_frac_last_tick": float(a4[-1, 0] + a4[-1, 1]) / T4}
+        m4.close()
 
     # ---- roofline (rank 0; HIP events on the launch stream, accumulated over the timed ticks)
     roofline = None
@@ -485,13 +572,20 @@ def main():
         out = {
             "metric": "MPC solves/sec (N=40, nx=8 [7 + progress s], nu=2)", "value": value, "unit": "MPC solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"batch={B} per GPU x {world} GPU, horizon N={N}, closed-loop warm ticks "
+            "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks on one GPU, gloo collectives - not a measurement",
+            "config": {"workload": (f"batch={n_total} in TOTAL sharded over {world} GPU(s) ({B} on rank 0)" if args.total_batch else f"batch={B} per GPU x {world} GPU")
+                                   + f", horizon N={N}, closed-loop warm ticks "
                                    f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
-                       "batch_per_gpu": B, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
-                       "resto_rho": opts.resto_rho, "resto_sticky": args.resto_sticky, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
-            "value_counts": "converged solves only (status solved / acceptable)",
+                       "batch_per_gpu": B, "total_batch": n_total, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
+                       "resto_rho": opts.resto_rho, "resto_sticky": args.resto_sticky, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; controls gathered per tick (RCCL all_gather)" if world > 1 else "1 GPU",
+                       "resto_rho_max": opts.resto_rho_max, "dual_inf_max": opts.dual_inf_max, "node0_check": opts.node0_check, "resto_shift_retry": opts.resto_shift_retry},
+            "value_counts": "converged solves only (status solved / acceptable, after the node-0 rule: an instance whose measured state is outside "
+                            "the track band counts as INFEASIBLE like the reference's NLP, whatever its solve did)",
             "solves_attempted_per_s": attempted,
+            "solver_converged_solves_per_s": solver_value,
+            "solver_status_histogram_last_tick": {STATUS_NAMES[k]: int(v) for k, v in enumerate(scounts[-1]) if v},
+            "gather_ms": gather_ms, "config4_total_8192": config4,
             "solved_frac_per_tick": [round(float(v) / n_all, 5) for v in converged_per_tick],
             "solved_frac_last_tick": float(converged_per_tick[-1]) / n_all,
             "status_histogram_last_tick": hist_last,

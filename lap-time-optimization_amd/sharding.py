@@ -20,10 +20,15 @@ def gather_rows(local: torch.Tensor, batch: int, rank: int, world: int) -> torch
         return local
     cols = local.shape[1]
     size = (batch + world - 1) // world
-    pad = torch.zeros(size, cols, dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    # (gloo, the backend of the CPU tests and of the one-GPU rehearsal of bench.py, gathers host tensors only; RCCL gathers in place)
+    dev = local.device
+    coll = torch.device("cpu") if (local.is_cuda and dist.get_backend() == "gloo") else dev
+    pad = torch.zeros(size, cols, dtype=local.dtype, device=coll)
+    pad[: local.shape[0]] = local.to(coll)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
+    if coll != dev:
+        parts = [q.to(dev) for q in parts]
     out = []
     for r in range(world):
         lo, hi = shard_range(batch, r, world)

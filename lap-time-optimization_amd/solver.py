@@ -159,6 +159,12 @@ class BatchedMPC:
         check(lib().ltompc_get_status_counts(self._h, iptr(c), C.byref(s)))
         return c, int(s.value)
 
+    def solver_status_counts(self):
+        """Histogram [8] of the solver's own statuses (before the node-0 rule), as reduced by the last status_counts() call."""
+        c = np.zeros(8, dtype=np.int32)
+        check(lib().ltompc_get_solver_status_counts(self._h, iptr(c)))
+        return c
+
     def history(self):
         buf = np.zeros((4096, 3), dtype=np.int32)
         n = lib().ltompc_get_history(self._h, iptr(buf), 4096)

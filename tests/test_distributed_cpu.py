@@ -74,6 +74,19 @@ def test_bench_launcher_starts_the_ranks_itself(tmp_path):
     assert r["converged_solves"] == 3 * (100 + 99)            # summed over the ranks (rank 1 "fails" one instance per tick)
     assert r["ms_per_step"] >= 4.0                              # the slower rank (2 x 2 ms per tick) sets the time
     assert r["value"] == pytest.approx(r["converged_solves"] / (r["ms_per_step"] * 3e-3), rel=1e-9)
+    # the same command also measured BASELINE config 4's shape (8192 in TOTAL over the ranks: strong scaling), with the per-tick
+    # gather of the controls over the process group
+    c4 = r["config4_total_8192"]
+    assert r["scaling"] == "weak" and c4["scaling"] == "strong" and c4["total_batch"] == 8192 and c4["batch_per_gpu"] == 4096
+    assert c4["converged_solves"] == 3 * (4096 + 4095)
+    assert r["gathered_checksum"] == sum(2.0 * (sum(range(200)) + 200 * k) for k in range(3))     # every rank's rows arrived, in order
+    # --total-batch makes that shape the headline
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--total-batch", "101",
+                          "--selftest-stub"], env=dict(env, MASTER_PORT="29549"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r2 = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert r2["scaling"] == "strong" and r2["config"]["total_batch"] == 101 and r2["config"]["batch_per_gpu"] == 51 and "config4_total_8192" not in r2
+    assert r2["converged_solves"] == 2 * (51 + 49)
     # one rank: no child process, same line format
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "0", "--batch", "10", "--selftest-stub"],
                          env=env, capture_output=True, text=True, timeout=120)
