@@ -4,12 +4,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))));
 T = ltompc.build_tables()
 B, N = 8192, 40
 x0 = ltompc.sample_x0(T, B)
-o = ltompc.default_options(); o.max_iter = 150
+o = ltompc.default_options()
 m = ltompc.BatchedMPC(T, N, B, options=o); m.set_initial_guess(x0)
 u0 = m.make_step(x0)
-for tick in range(3):
+NT = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+for tick in range(NT):
     x0 = m.plant_step(x0, u0)
-    m.set_profiling(tick == 2)
+    m.set_profiling(tick == NT - 1)
     t0 = time.perf_counter(); u0 = m.make_step(x0); dt = time.perf_counter() - t0
 kind, width, ms = m.launch_log()
 names = ["eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1"]
