@@ -185,6 +185,13 @@ typedef struct ltompc_options {
                              converges needs ~60 at most on this NLP; one cycling instance running to max_iter = 1000 costs a
                              tick of 8192 instances 200 ms).  On the hard constraints the recovery steps take over (shifted
                              restart, restoration phase), elsewhere the solve ends with status STALLED.  0 = off.        (100) */
+  int infeasible_sticky;  /* 1: a warm-started solve that follows one the solver ended INFEASIBLE (its own verdict, at the largest
+                             penalty - not the node-0 rule) starts where that one ended: in the escalated elastic problem, from
+                             its primal point and multipliers, instead of going through hard attempt, shifted restart and the
+                             elastic problem at resto_rho again (~100 passes; a car that cannot make the corner stays infeasible
+                             for several ticks, and such chronic cases are the slowest instances of every tick).  It ends like
+                             any restoration: back on the hard constraints when every elastic variable is <= tol (SOLVED),
+                             INFEASIBLE otherwise.  0: every solve starts on the hard constraints (IPOPT).              (1) */
   int latency_mode;       /* which evaluation kernels a handle uses, fixed at create: 2 = thread per (interval, instance)
                              (fewest instructions per instance: throughput), 1 = 8 lanes per (interval, instance)
                              (k_eval8 / k_expand8: a third of the latency per launch, 3x the time at full load),

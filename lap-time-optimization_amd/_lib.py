@@ -31,7 +31,7 @@ class Options(C.Structure):
         "resto_rho_max", "resto_rho_factor", "dual_inf_max")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
         ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("resto_sticky", C.c_int),
-        ("node0_check", C.c_int), ("warm_fallback_iter", C.c_int), ("resto_shift_retry", C.c_int), ("max_mu_stay", C.c_int), ("latency_mode", C.c_int)]
+        ("node0_check", C.c_int), ("warm_fallback_iter", C.c_int), ("resto_shift_retry", C.c_int), ("max_mu_stay", C.c_int), ("infeasible_sticky", C.c_int), ("latency_mode", C.c_int)]
 
 
 class LtompcError(RuntimeError):

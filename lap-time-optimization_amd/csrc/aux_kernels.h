@@ -31,9 +31,12 @@ __device__ __forceinline__ void d_init_slot(const Consts& K, const Work& W, cons
   // its next solves in the restoration phase's elastic mode (the counter is kept by k_load_x0); the multipliers of a
   // converged ELASTIC problem (status INFEASIBLE) are then re-used like any others.
   const bool resto_ok = K.o.resto_rho > 0.0 && !(K.o.soft_rho > 0.0);
-  const bool start_elastic = !cold && resto_ok && K.o.resto_sticky > 0 && W.si[(size_t)SI_STICKY * W.Bp + b] > 0;
+  // Option infeasible_sticky: the solve before this one ended INFEASIBLE (the solver's verdict, at the largest penalty): this one
+  // starts where that one ended, in the escalated elastic problem, from its primal point and multipliers.
+  const bool inf_sticky = !cold && resto_ok && K.o.infeasible_sticky && prev == LTOMPC_STATUS_INFEASIBLE;
+  const bool start_elastic = inf_sticky || (!cold && resto_ok && K.o.resto_sticky > 0 && W.si[(size_t)SI_STICKY * W.Bp + b] > 0);
   const bool prev_conv = prev == LTOMPC_STATUS_SOLVED || prev == LTOMPC_STATUS_ACCEPTABLE ||
-                         (prev == LTOMPC_STATUS_INFEASIBLE && K.o.resto_sticky > 0);
+                         (prev == LTOMPC_STATUS_INFEASIBLE && (K.o.resto_sticky > 0 || K.o.infeasible_sticky));
   const bool after_failure = !cold && K.o.warm_reset_on_fail && !prev_conv;
   if (after_failure) {
 #pragma unroll
@@ -52,7 +55,7 @@ __device__ __forceinline__ void d_init_slot(const Consts& K, const Work& W, cons
   }
   const double mu_s = (!cold && !after_failure && K.o.mu_init_warm > 0) ? K.o.mu_init_warm : K.o.mu_init;
   const double eps = (K.o.smooth_scale > 0 || K.o.smooth_eps_min > 0) ? fmax(K.o.smooth_eps_min, K.o.smooth_scale * mu_s) : 0.0;
-  const double rho = start_elastic ? K.o.resto_rho : K.o.soft_rho;  // (the restoration phase replaces it per instance, see d_pick)
+  const double rho = inf_sticky ? fmax(K.o.resto_rho, K.o.resto_rho_max) : (start_elastic ? K.o.resto_rho : K.o.soft_rho);  // (the restoration phase replaces it per instance, see d_pick)
   const double mu = mu_s * pen_scale(rho);  // (penalty scale, layout.h: 1 unless rho > RHO_UNIT)
   init_slot_slacks<BoundsAny>(K, W, k, b, mu, eps, rho, xp, c, u);
   if (k == 0) {

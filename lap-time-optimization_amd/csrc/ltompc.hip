@@ -275,7 +275,7 @@ void ltompc_default_options(ltompc_options* o) {
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
-  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->infeasible_sticky = 1, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
 }
 
 int ltompc_create(const ltompc_params* params, const ltompc_options* options, const double* tables, int n_table,

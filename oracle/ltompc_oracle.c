@@ -680,6 +680,7 @@ typedef struct {
   int n_reg, n_lsfail, n_soc, n_resto, n_fallback, n_shift;
   double viol; /* largest elastic variable at termination (0 on the hard constraints); g0 when node 0 decided the status */
   double g0;   /* largest track constraint at the measured state (options.node0_check) */
+  double rho_end; /* penalty of the elastic variables at termination (0: hard constraints) */
   int trig; /* diagnostics (experiment): bit 0 / 1: the early-stall rule fired before / after the shifted restart */
   int mu_stay_max; /* diagnostics: longest run of iterations without a decrease of the barrier parameter */
   double rd_max; /* diagnostics: largest dual infeasibility (in the units of the penalty scale) any iterate of the solve had */
@@ -1148,8 +1149,11 @@ static int solve_one(const ltompc_params* p, const ltompc_options* o, const tabl
   double S = PEN_SCALE(it->rho); /* (soft_rho) */
   const int resto_allowed = o->resto_rho > 0 && !(o->soft_rho > 0);
   if (start_elastic && resto_allowed && warm) { /* (slacks and elastic variables below: init_slacks with rho = resto_rho) */
+    /* start_elastic = 2 (options.infeasible_sticky): the solve before this one ended INFEASIBLE, at the largest penalty; this one
+     * starts where that one ended - in the escalated elastic problem, from its primal point and its multipliers */
+    const double rho_start = start_elastic == 2 ? fmax(o->resto_rho, o->resto_rho_max) : o->resto_rho;
     resto = 1, st->n_resto = 1;
-    it_set_rho(it, o->resto_rho, p), it_set_rho(tr, o->resto_rho, p);
+    it_set_rho(it, rho_start, p), it_set_rho(tr, rho_start, p);
     S = PEN_SCALE(it->rho);
     mu = s->mu = mu * S; /* (the barrier parameter chosen above is in scaled units; soft_rho = 0 here) */
     init_slacks(s);
@@ -1572,7 +1576,7 @@ done:
   if (it->rho > 0)
     for (int k = 0; k + 1 < N; k++)
       for (int q = 0; q < NNL; q++) st->viol = fmax(st->viol, it->e[k * NNLT + q]);
-  st->g0 = -INFINITY, st->status_solver = status;
+  st->g0 = -INFINITY, st->status_solver = status, st->rho_end = it->rho;
   if (o->node0_check && !(o->soft_rho > 0)) {
     /* do_mpc registers the track constraints at node 0 as well (controller.py:69-70): rows that only involve the
      * measured state.  They cannot change the minimiser, but a measured state outside the band leaves the reference's NLP
@@ -1620,7 +1624,7 @@ void oracle_default_options(ltompc_options* o) {
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0, o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->resto_rho = 1000.0, o->max_soc = 0, o->resto_sticky = 0;
   o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
-  o->dual_inf_max = 1e4, o->max_mu_stay = 100;
+  o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->infeasible_sticky = 1;
   o->warm_reset_on_fail = 1; /* applied by the caller (oracle.py solve(prev_status=...)): this file sees one solve at a time */
 }
 
@@ -1751,10 +1755,12 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
     if (warm && prev_status) {
       const int ps = prev_status[b];
       /* with resto_sticky the multipliers of a converged ELASTIC problem (status INFEASIBLE) are re-used like any others */
-      const int conv = ps == LTOMPC_STATUS_SOLVED || ps == LTOMPC_STATUS_ACCEPTABLE || (ps == LTOMPC_STATUS_INFEASIBLE && o->resto_sticky > 0);
+      const int conv = ps == LTOMPC_STATUS_SOLVED || ps == LTOMPC_STATUS_ACCEPTABLE ||
+                       (ps == LTOMPC_STATUS_INFEASIBLE && (o->resto_sticky > 0 || o->infeasible_sticky));
       if (o->warm_reset_on_fail && !conv) w = 2;
+      if (ps == LTOMPC_STATUS_INFEASIBLE && o->infeasible_sticky) start_elastic = 2;
     }
-    if (warm && sticky && o->resto_sticky > 0 && sticky[b] > 0) start_elastic = 1;
+    if (warm && sticky && o->resto_sticky > 0 && sticky[b] > 0 && !start_elastic) start_elastic = 1;
     solve_one(p, o, &T, N, x0 + (size_t)b * NX, uprev + (size_t)b * NU, w, start_elastic, X + (size_t)b * (N + 1) * NX,
               C + (size_t)b * N * NX, U + (size_t)b * N * NU, L1 + (size_t)b * N * NX, L2 + (size_t)b * N * NX,
               Tout ? Tout + (size_t)b * N * ni0 : NULL, NUout ? NUout + (size_t)b * N * ni0 : NULL, &st);
@@ -1766,9 +1772,9 @@ int oracle_solve_batch(const ltompc_params* p, const ltompc_options* o, const do
       else if (sticky[b] > 0) sticky[b]--;
     }
     u0[b * NU] = U[(size_t)b * N * NU], u0[b * NU + 1] = U[(size_t)b * N * NU + 1];
-    double* s = stats + (size_t)b * 17;
+    double* s = stats + (size_t)b * 18;
     s[0] = st.status, s[1] = st.iters, s[2] = st.kkt, s[3] = st.obj, s[4] = st.mu, s[5] = st.n_reg, s[6] = st.n_lsfail;
-    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol, s[10] = st.g0, s[11] = st.n_fallback, s[12] = st.n_shift, s[13] = st.status_solver, s[14] = st.rd_max, s[15] = st.mu_stay_max, s[16] = st.trig;
+    s[7] = st.n_soc, s[8] = st.n_resto, s[9] = st.viol, s[10] = st.g0, s[11] = st.n_fallback, s[12] = st.n_shift, s[13] = st.status_solver, s[14] = st.rd_max, s[15] = st.mu_stay_max, s[16] = st.trig, s[17] = st.rho_end;
   }
   return 0;
 }

@@ -32,7 +32,7 @@ class Options(C.Structure):
         "resto_rho_max", "resto_rho_factor", "dual_inf_max")] + [
         ("max_iter", C.c_int), ("acceptable_iter", C.c_int), ("n_linesearch", C.c_int), ("stall_iter", C.c_int),
         ("max_ls_fail", C.c_int), ("warm_shift", C.c_int), ("warm_reset_on_fail", C.c_int), ("periodic_tables", C.c_int), ("max_soc", C.c_int), ("resto_sticky", C.c_int),
-        ("node0_check", C.c_int), ("warm_fallback_iter", C.c_int), ("resto_shift_retry", C.c_int), ("max_mu_stay", C.c_int), ("latency_mode", C.c_int)]
+        ("node0_check", C.c_int), ("warm_fallback_iter", C.c_int), ("resto_shift_retry", C.c_int), ("max_mu_stay", C.c_int), ("infeasible_sticky", C.c_int), ("latency_mode", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -141,7 +141,7 @@ class Oracle:
             L1, L2 = np.zeros((B, N, 8)), np.zeros((B, N, 8))
         else:
             X, Cc, U, L1, L2 = (np.ascontiguousarray(warm[k], float).copy() for k in ("X", "C", "U", "L1", "L2"))
-        u0, st = np.zeros((B, 2)), np.zeros((B, 17))
+        u0, st = np.zeros((B, 2)), np.zeros((B, 18))
         ni = int(lib().oracle_num_ineq(C.byref(self.p)))
         Tt, Nu = np.zeros((B, N, ni)), np.zeros((B, N, ni))
         ps = None
@@ -161,7 +161,7 @@ class Oracle:
         return dict(u0=u0, X=X, C=Cc, U=U, L1=L1, L2=L2, T=Tt, NU=Nu, status=st[:, 0].astype(int), iters=st[:, 1].astype(int),
                     kkt=st[:, 2], obj=st[:, 3], mu=st[:, 4], n_reg=st[:, 5].astype(int), n_lsfail=st[:, 6].astype(int),
                     n_soc=st[:, 7].astype(int), n_resto=st[:, 8].astype(int), viol=st[:, 9], g0=st[:, 10],
-                    n_fallback=st[:, 11].astype(int), n_shift=st[:, 12].astype(int), status_solver=st[:, 13].astype(int), rd_max=st[:, 14], mu_stay_max=st[:, 15].astype(int), trig=st[:, 16].astype(int))
+                    n_fallback=st[:, 11].astype(int), n_shift=st[:, 12].astype(int), status_solver=st[:, 13].astype(int), rd_max=st[:, 14], mu_stay_max=st[:, 15].astype(int), trig=st[:, 16].astype(int), penalty=st[:, 17])
 
 
 class VpVehicle(C.Structure):

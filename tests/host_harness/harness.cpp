@@ -50,7 +50,7 @@ static void default_options(ltompc_options* o) {  // = ltompc_default_options
   o->s_max = 100, o->delta_w_first = 1e-4, o->smooth_eps_min = 1e-4, o->smooth_scale = 1.0;
   o->max_iter = 1000, o->acceptable_iter = 15, o->n_linesearch = 8, o->stall_iter = 15, o->max_ls_fail = 8;
   o->warm_reset_on_fail = 1, o->resto_rho = 1000.0;
-  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
+  o->resto_rho_max = 1e6, o->resto_rho_factor = 1e3, o->dual_inf_max = 1e4, o->max_mu_stay = 100, o->infeasible_sticky = 1, o->node0_check = 1, o->warm_fallback_iter = 25, o->resto_shift_retry = 1;
 }
 // further options as key=value arguments (tests of the option paths)
 static bool set_option(ltompc_options* o, const char* arg) {
@@ -61,7 +61,7 @@ static bool set_option(ltompc_options* o, const char* arg) {
 #define OPT_D(name) if (key == #name) { o->name = v; return true; }
 #define OPT_I(name) if (key == #name) { o->name = (int)v; return true; }
   OPT_D(dual_inf_max) OPT_D(resto_rho) OPT_D(resto_rho_max) OPT_D(resto_rho_factor) OPT_D(mu_init_warm) OPT_D(tol) OPT_D(mu_init)
-  OPT_I(max_mu_stay) OPT_I(node0_check) OPT_I(warm_fallback_iter) OPT_I(resto_shift_retry) OPT_I(warm_shift) OPT_I(resto_sticky) OPT_I(max_iter)
+  OPT_I(infeasible_sticky) OPT_I(max_mu_stay) OPT_I(node0_check) OPT_I(warm_fallback_iter) OPT_I(resto_shift_retry) OPT_I(warm_shift) OPT_I(resto_sticky) OPT_I(max_iter)
   OPT_I(warm_reset_on_fail) OPT_I(stall_iter)
 #undef OPT_D
 #undef OPT_I

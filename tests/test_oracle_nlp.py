@@ -251,7 +251,7 @@ def _reference_loop(orc, oracle, tables, N, ticks, certify):
         hist[s] = hist.get(s, 0) + 1; hist_solver[ss] = hist_solver.get(ss, 0) + 1
         assert ss in (0, 1, 5), (tick, ss)
         if ss == 5:   # the solver's own verdict: only at the largest penalty, and certified
-            assert s == 5 and r["viol"][0] > 1e-8 and r["n_resto"][0] >= 2, (tick, r["viol"][0], r["n_resto"][0])
+            assert s == 5 and r["viol"][0] > 1e-8 and r["penalty"][0] == oracle.o.resto_rho_max, (tick, r["viol"][0], r["penalty"][0])
             if certify:
                 _certify_infeasible(orc, tables, x, up, warm, r, N, rng)
         elif s == 5:  # the node-0 rule: the measured state is outside the band, the solve itself converged
@@ -288,7 +288,7 @@ def test_round2_false_infeasibles_are_solved(orc, tables):
     restart) ended ticks 152 and 227 of the reference's loop INFEASIBLE although a feasible point exists (the
     elastic problem drifts into a local minimum of the violation; tick 227 is round 2's "tick 228").  With the defaults - the
     shifted restart first - both are SOLVED on the hard constraints, the restoration phase is not even entered."""
-    o = orc.default_options(); o.resto_rho_factor, o.resto_shift_retry, o.node0_check = 1.0, 0, 0
+    o = orc.default_options(); o.resto_rho_factor, o.resto_shift_retry, o.node0_check, o.infeasible_sticky, o.dual_inf_max, o.max_mu_stay = 1.0, 0, 0, 0, 0.0, 0
     old, new = orc.Oracle(tables.packed(), options=o), orc.Oracle(tables.packed())
     x, warm, st, up = np.array([[0, 0, 0, 5, 0, 0, 0, 0.1]], float), None, None, np.zeros((1, 2))
     seen = {}
