@@ -1,8 +1,21 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def _rate(name, value, minimum):
+    """A measured agreement rate against its threshold; LTOMPC_TEST_RATES=<file> logs the measured values (how the thresholds
+    were set: the measured rate less a stated margin)."""
+    f = os.environ.get("LTOMPC_TEST_RATES")
+    if f:
+        with open(f, "a") as fh:
+            fh.write(f"{name} {float(value):.4f} (min {minimum})\n")
+    assert value >= minimum, (name, float(value), minimum)
+
 
 X0_REF = np.array([[0, 0, 0, 5, 0, 0, 0, 0.1]], dtype=float)
 
@@ -508,14 +521,15 @@ def test_warm_reset_after_a_failed_solve(pkg, tables, orc, gpu_lib):
         mm.make_step(xbad)
         r1 = oracle.solve(xbad, N, nthreads=8)
         # (locally infeasible problems: INFEASIBLE after 100 - 200 iterations, a few at the iteration limit on one side only)
-        assert (mm.status != 0).mean() > 0.8 and np.array_equal(mm.status != 0, r1["status"] != 0) and (mm.status == r1["status"]).mean() >= 0.75
+        assert (mm.status != 0).mean() > 0.8 and np.array_equal(mm.status != 0, r1["status"] != 0)
+        _rate(f"warm_reset[{reset}].tick1.status", (mm.status == r1["status"]).mean(), 0.93)   # measured 1.0; one of 16 may differ
         u2 = mm.make_step(x0)   # back on the track: warm start from the failed solve
         r2 = oracle.solve(x0, N, uprev=r1["u0"], warm=r1, nthreads=8, prev_status=r1["status"])
         both = (mm.status == 0) & (r2["status"] == 0)
-        assert both.mean() >= 0.9, (reset, both.mean())
-        assert (mm.status == r2["status"]).mean() >= 0.9
+        _rate(f"warm_reset[{reset}].tick2.both", both.mean(), 0.93)   # measured 1.0
+        _rate(f"warm_reset[{reset}].tick2.status", (mm.status == r2["status"]).mean(), 0.93)
         assert np.abs(u2 - r2["u0"])[both].max() < 1e-5
-        assert (np.abs(mm.iters - r2["iters"])[both] <= 2).mean() >= 0.85
+        _rate(f"warm_reset[{reset}].tick2.iters", (np.abs(mm.iters - r2["iters"])[both] <= 2).mean(), 0.93)   # measured 1.0
         res[reset] = (mm.iters.copy(), mm.status.copy())
         mm.close()
     # the reset is not a no-op: iteration counts differ between the two policies
@@ -955,9 +969,10 @@ def test_exact_piecewise_linear_tables_on_gpu(pkg, tables, orc, gpu_lib):
         m.set_initial_guess(x0)
         u = m.make_step(x0)
         both = (m.status == 0) & (ref["status"] == 0)
-        assert both.mean() >= 0.8 and both[0], (mode, both.mean(), m.status, ref["status"])
+        _rate(f"exact_pwl[{mode}].both", both.mean(), 0.95)   # measured 1.0; one of 24 may differ
+        assert both[0], (mode, m.status, ref["status"])
         assert np.abs(u - ref["u0"])[both].max() < 1e-5, mode
-        assert np.array_equal(np.isin(m.status, (0, 1)), np.isin(ref["status"], (0, 1))) or (m.status == ref["status"]).mean() >= 0.9
+        _rate(f"exact_pwl[{mode}].status", (m.status == ref["status"]).mean(), 0.95)
         m.close()
     d = pkg.BatchedMPC(tables, N, B)
     d.set_initial_guess(x0)
@@ -992,7 +1007,7 @@ def test_sticky_elastic_start_matches_oracle(pkg, tables, orc, gpu_lib):
         assert (s["n_resto"] == ref["n_resto"]).mean() >= 0.97, tick
         both = (s["status"] == 0) & (ref["status"] == 0)
         assert np.abs(u - ref["u0"])[both].max() < 1e-5, tick
-        assert (np.abs(s["iters"] - ref["iters"])[both] <= 2).mean() >= 0.93, tick
+        _rate(f"sticky.tick{tick}.iters", (np.abs(s["iters"] - ref["iters"])[both] <= 2).mean(), 0.96)   # measured 0.979 .. 1.0
         if started.any():   # an elastic start ends like any restoration: SOLVED on the hard constraints or INFEASIBLE with a violation
             assert np.all(s["n_resto"][started & (s["status"] == ref["status"])] >= 1)
             assert np.all(s["viol"][s["status"] == 5] > o.tol)
@@ -1071,9 +1086,10 @@ def test_friction_ellipse_constraints_on_gpu(pkg, tables, orc, gpu_lib):
         s = mpc.stats()
         ref = oracle.solve(xx, N, up, ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (s["status"] == 0) & (ref["status"] == 0)
-        assert (s["status"] == ref["status"]).mean() >= 0.9 and both.mean() >= 0.8, (tick, s["status"], ref["status"])
+        _rate(f"ellipse.tick{tick}.status", (s["status"] == ref["status"]).mean(), 0.93)   # measured 0.969 .. 1.0 (32 instances)
+        _rate(f"ellipse.tick{tick}.both", both.mean(), 0.93)
         assert np.abs(u - ref["u0"])[both].max() < 1e-5, tick
-        assert (np.abs(s["iters"] - ref["iters"])[both] <= 3).mean() >= 0.85, tick
+        _rate(f"ellipse.tick{tick}.iters", (np.abs(s["iters"] - ref["iters"])[both] <= 3).mean(), 0.84)   # measured 0.875 .. 0.97: the soft ellipse constraints make long, chaotic solves
         assert np.abs(s["obj"] - ref["obj"])[both].max() < 1e-6 * max(1.0, np.abs(ref["obj"][both]).max())
         if tick == 0:
             assert np.abs(ref["u0"] - base["u0"]).max() > 1e-3       # the constraints change the solutions ...
