@@ -100,6 +100,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
+    ap.add_argument("--parts", type=int, default=0, help="handles the batch of a GPU is split into, each on its own HIP stream and host thread, ticking at "
+                    "its own pace (SplitMPC: one part's narrow tail overlaps the other's full-width launches; results bit-identical to one "
+                    "handle).  0 = 2 on one GPU, 1 with several GPUs (the per-tick RCCL gather of the controls needs the whole rank's tick)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances in TOTAL, sharded over the GPUs in contiguous "
                     "blocks (BASELINE config 4: 8192); 0 = weak scaling with --batch instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
@@ -235,10 +238,19 @@ def main():
     B, n_total = hi - lo, (args.total_batch if args.total_batch else args.batch * world)
     opts = ltompc.default_options()
     opts.max_iter, opts.soft_rho, opts.resto_sticky = args.max_iter, args.soft_rho, args.resto_sticky
-    mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
+    n_parts = args.parts if args.parts > 0 else (2 if world == 1 else 1)
+    split = n_parts > 1
+    if split and world > 1:
+        raise SystemExit("bench.py: --parts > 1 is for one GPU (with several ranks the controls are gathered every tick, which needs the rank's whole tick)")
     stream = torch.cuda.current_stream(dev)
-    mpc.set_stream(stream.cuda_stream)
+    if split:
+        mpc = ltompc.SplitMPC(tables, n_horizon=N, batch=B, n_parts=n_parts, options=opts, device=local_rank)  # (each part on its own stream)
+    else:
+        mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
+        mpc.set_stream(stream.cuda_stream)
     mpc.set_poll_every(args.poll_every)
+    prof = mpc.parts[0] if split else mpc   # the handle whose launches are logged (roofline accounting): B_acc instances
+    B_acc = prof.B
 
     # weak scaling: every rank samples its own 8192 states; strong scaling: ONE batch of n_total states, rank r holds rows [lo, hi)
     x0_host = ltompc.sample_x0(tables, n_total, seed=ltompc.scenarios.SEED)[lo:hi] if args.total_batch else ltompc.sample_x0(tables, B, seed=ltompc.scenarios.SEED + rank)
@@ -247,6 +259,14 @@ def main():
     u = torch.zeros(B, 2, dtype=torch.float64, device=dev)
 
     gather_ev = []  # (start, end) events around the gather of every timed tick
+
+    def run_split(k, after_tick=None):
+        """k ticks of every part at its own pace (SplitMPC.run_ticks); the states end in x"""
+        nonlocal x, xn
+        torch.cuda.synchronize(dev)
+        mpc.run_ticks(x.data_ptr(), u.data_ptr(), xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after_tick)
+        if k % 2:
+            x, xn = xn, x
 
     def tick(timed=False):
         nonlocal x, xn
@@ -271,14 +291,22 @@ def main():
     #      in the last of them: which kernel class takes the most device time (the one the roofline is quoted for; all 8
     #      classes compete) and the per-class totals come from that tick; the timed ticks bracket the launches of that class
     #      only (two events per iteration instead of seven: the full bracketing costs 4 % of the throughput, one class 1 %).
-    mpc.set_initial_guess_dev(x.data_ptr())
-    for w in range(args.warmup):
-        if w == args.warmup - 1:
-            mpc.set_profiling(not args.no_profile)  # the last warm-up tick (a warm one if W >= 2), like the timed ticks
-        tick()
     torch.cuda.synchronize(dev)
-    tm_warm = mpc.timing() if (not args.no_profile and args.warmup > 0) else None
-    log_warm = mpc.launch_log(with_iterations=True) if tm_warm is not None else None  # every launch of that tick, by class and width
+    mpc.set_initial_guess_dev(x.data_ptr())
+    if split:
+        if args.warmup > 1:
+            run_split(args.warmup - 1)
+        if args.warmup > 0:
+            mpc.set_profiling(not args.no_profile)
+            run_split(1)
+    else:
+        for w in range(args.warmup):
+            if w == args.warmup - 1:
+                mpc.set_profiling(not args.no_profile)  # the last warm-up tick (a warm one if W >= 2), like the timed ticks
+            tick()
+    torch.cuda.synchronize(dev)
+    tm_warm = prof.timing() if (not args.no_profile and args.warmup > 0) else None
+    log_warm = prof.launch_log(with_iterations=True) if tm_warm is not None else None  # every launch of that tick, by class and width
     dom = max(tm_warm["ms"], key=lambda k: tm_warm["ms"][k]) if tm_warm is not None else None
 
     # ---- timed region: exactly K ticks.  After every tick: the device-side histogram of the statuses (one tiny kernel
@@ -289,20 +317,39 @@ def main():
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     per_tick_solver = []
-    for _ in range(args.steps):
-        tick(timed=True)
-        c, isum = mpc.status_counts()
-        per_tick_counts.append(c), per_tick_itersum.append(isum)
-        per_tick_solver.append(mpc.solver_status_counts())
-        per_tick_iters.append(mpc.timing()["ip_iterations"])
-        if not args.no_profile:
-            active_hist.append(mpc.active_history())
+    extra_inst_iters = 0.0  # instance-iterations of the parts whose launches are not logged (tick-level roofline)
+    if split:
+        # every part runs its K ticks at its own pace; after each of ITS ticks (in its thread): the status histograms and the
+        # per-iteration counts of unfinished instances, exactly what the single handle records
+        rec = [[None] * args.steps for _ in range(n_parts)]
+        def after(pi, t):
+            q = mpc.parts[pi]
+            c, isum = q.status_counts()
+            rec[pi][t] = (c, isum, q.solver_status_counts(), q.timing()["ip_iterations"], q.active_history() if not args.no_profile else None)
+        run_split(args.steps, after_tick=after)
+        for t in range(args.steps):
+            per_tick_counts.append(sum(rec[pi][t][0] for pi in range(n_parts)))
+            per_tick_itersum.append(sum(rec[pi][t][1] for pi in range(n_parts)))
+            per_tick_solver.append(sum(rec[pi][t][2] for pi in range(n_parts)))
+            per_tick_iters.append(max(rec[pi][t][3] for pi in range(n_parts)))
+            if not args.no_profile:
+                active_hist.append(rec[0][t][4])
+                extra_inst_iters += sum(mpc.parts[pi].B + float(rec[pi][t][4][:max(0, rec[pi][t][3] - 1)].sum()) for pi in range(1, n_parts))
+    else:
+        for _ in range(args.steps):
+            tick(timed=True)
+            c, isum = mpc.status_counts()
+            per_tick_counts.append(c), per_tick_itersum.append(isum)
+            per_tick_solver.append(mpc.solver_status_counts())
+            per_tick_iters.append(mpc.timing()["ip_iterations"])
+            if not args.no_profile:
+                active_hist.append(mpc.active_history())
     torch.cuda.synchronize(dev)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    tm = mpc.timing()
-    log = mpc.launch_log(with_iterations=True) if not args.no_profile else None
+    tm = prof.timing()
+    log = prof.launch_log(with_iterations=True) if not args.no_profile else None
     mpc.set_profiling(False)
 
     counts = np.array(per_tick_counts, dtype=np.float64)  # (K, 8)
@@ -378,7 +425,7 @@ def main():
             tick_of_launch[i] = tk
         def active_in(tk, it):
             a = active_hist[min(tk, len(active_hist) - 1)]
-            return B if it == 0 else (int(a[it - 1]) if it - 1 < len(a) else 0)
+            return B_acc if it == 0 else (int(a[it - 1]) if it - 1 < len(a) else 0)
         sel = kind == names.index(dom)
         act = np.array([min(active_in(int(tick_of_launch[i]), int(lit[i])), int(width[i])) for i in np.where(sel)[0]], dtype=np.float64)
         avg_ms = float(lms[sel].mean())
@@ -393,21 +440,23 @@ def main():
                     "kernel_ms_total_from": ("the last warm-up tick, every launch bracketed"
                                              if tm_warm else "the timed ticks, every launch bracketed"),
                     "timed_region_events": ("launches of " + KERNEL_OF_CLASS[dom] + " only") if tm_warm else "every launch"}
-        pmc = load_pmc_traffic(KERNEL_OF_CLASS[dom], B, N)
+        pmc = load_pmc_traffic(KERNEL_OF_CLASS[dom], B_acc, N)
+        roofline["accounting"] = (f"launches of ONE of the {n_parts} handles the batch is split into ({B_acc} instances; 'full width' = all of them), "
+                                  "measured while the other handle's kernels run beside them" if split else f"the one handle of {B} instances")
         if pmc:
             roofline["traffic"] = pmc.get("traffic_avg_all_launches")
             roofline["traffic_source"] = pmc["source"]
         # the whole tick against the same roof: every (instance, interval, iteration) moves 3104 algorithmic bytes
-        inst_iters = float(np.mean([B + float(a[:max(0, n - 1)].sum()) for a, n in zip(active_hist, per_tick_iters)]))
+        inst_iters = float(np.mean([B_acc + float(a[:max(0, len(a) - 1)].sum()) for a in active_hist])) + extra_inst_iters / args.steps
         tick_bytes = inst_iters * N * BYTES_PER_STAGE_ITER
         ms_per_step = 1e3 * elapsed / args.steps
         roofline["tick"] = {"algorithmic_bytes_per_tick": tick_bytes, "instance_iterations_per_tick": inst_iters, "ms_per_step": ms_per_step,
                             "achieved": tick_bytes / (ms_per_step * 1e-3) / 1e9, "frac": tick_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the widest launches of the dominant class (every instance of the batch still iterating or idle in its wavefront)
-        full = sel & (width == B)
+        full = sel & (width == B_acc)
         if full.any():
             fw_ms = float(lms[full].mean())
-            fw_bytes = B * N * BYTES_BY_KERNEL[dom]
+            fw_bytes = B_acc * N * BYTES_BY_KERNEL[dom]
             roofline["full_width"] = {"launches": int(full.sum()), "avg_launch_ms": fw_ms, "algorithmic_bytes_per_launch": fw_bytes,
                                       "achieved": fw_bytes / (fw_ms * 1e-3) / 1e9, "frac": fw_bytes / (fw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if pmc:
@@ -418,9 +467,9 @@ def main():
             wk, ww, wms, _ = log_warm
             fwc = {}
             for ci, cname in enumerate(names):
-                s3 = (wk == ci) & (ww == B)
+                s3 = (wk == ci) & (ww == B_acc)
                 if s3.any() and BYTES_BY_KERNEL[cname] > 0:
-                    t_ms, by = float(wms[s3].mean()), B * N * BYTES_BY_KERNEL[cname]
+                    t_ms, by = float(wms[s3].mean()), B_acc * N * BYTES_BY_KERNEL[cname]
                     fwc[KERNEL_OF_CLASS[cname]] = {"launches": int(s3.sum()), "avg_launch_ms": round(t_ms, 4), "algorithmic_bytes_per_launch": by,
                                                    "achieved": round(by / (t_ms * 1e-3) / 1e9, 1), "frac": round(by / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             roofline["full_width_by_class"] = fwc
@@ -524,6 +573,8 @@ def main():
                                          "passes_per_instance": {"median": float(np.median(passes)), "p99": float(np.percentile(passes, 99)), "max": int(passes.max())},
                                          "full_width_iterations_equivalent": float(passes.sum()) / B}
         mr.close()
+        if split:  # the same workload on ONE handle of all B instances (what `value` was in rounds 1 and 2)
+            side_run(opts, "single_handle", {"parts": 1})
         # the same workload at round 1's iteration budget (150 instead of the reference's 1000)
         o150 = ltompc.default_options(); o150.max_iter, o150.soft_rho = 150, args.soft_rho
         side_run(o150, "max_iter_150", {"max_iter": 150})
@@ -575,9 +626,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if args.total_batch else "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks on one GPU, gloo collectives - not a measurement",
             "config": {"workload": (f"batch={n_total} in TOTAL sharded over {world} GPU(s) ({B} on rank 0)" if args.total_batch else f"batch={B} per GPU x {world} GPU")
+                                   + (f" (as {n_parts} handles of {B_acc}, each on its own stream, ticking at its own pace)" if split else "")
                                    + f", horizon N={N}, closed-loop warm ticks "
                                    f"(buckmore / MX-5 / curvature tables, x0 sampled along the lap, seed {ltompc.scenarios.SEED})",
-                       "batch_per_gpu": B, "total_batch": n_total, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
+                       "batch_per_gpu": B, "total_batch": n_total, "parts_per_gpu": n_parts, "horizon": N, "max_iter": args.max_iter, "tol": opts.tol, "soft_rho": args.soft_rho,
                        "resto_rho": opts.resto_rho, "resto_sticky": args.resto_sticky, "parallelism": f"instances sharded over {world} GPU(s), no data-path collective; controls gathered per tick (RCCL all_gather)" if world > 1 else "1 GPU",
                        "resto_rho_max": opts.resto_rho_max, "dual_inf_max": opts.dual_inf_max, "node0_check": opts.node0_check, "resto_shift_retry": opts.resto_shift_retry},
             "value_counts": "converged solves only (status solved / acceptable, after the node-0 rule: an instance whose measured state is outside "

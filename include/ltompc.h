@@ -233,6 +233,9 @@ int ltompc_make_step(ltompc_handle h, const double* x0, double* u0, int* status,
  * stream; the call returns after the last poll, the final u0 store may still be in flight on that stream. */
 int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev);
 
+/* Waits until everything the handle has enqueued on its stream (the _dev entry points only enqueue) has completed. */
+int ltompc_synchronize(ltompc_handle h);
+
 /* Closed-loop rollout with FREE-RUNNING instances: every instance does n_ticks of the reference's loop body (src/mpc.py:140-153:
  * u0 = make_step(x0); x0 = plant(x0, u0)), but an instance that has converged takes its plant step and starts its next tick
  * inside the running batch instead of waiting for the slowest instance of the tick (no coupling exists between instances;

@@ -6,7 +6,7 @@ or through the alias module `ltompc` at the repository root.
 """
 from .tables import TrackTables, build_tables  # noqa: F401
 from ._lib import LtompcError, Options, Params, default_options, default_params, STATUS_NAMES, NO_BOUND  # noqa: F401
-from .solver import BatchedMPC  # noqa: F401
+from .solver import BatchedMPC, SplitMPC  # noqa: F401
 from .mpc import Controller, Simulator, Track, VehicleModel, closed_loop  # noqa: F401
 from .scenarios import X0_REFERENCE, sample_x0  # noqa: F401
 from .velocity import Vehicle, VehicleMX5, VelocityProfile, VpVehicle  # noqa: F401

@@ -586,6 +586,13 @@ int ltompc_make_step_dev(ltompc_handle h, const double* x0_dev, double* u0_dev) 
   return 0;
 }
 
+int ltompc_synchronize(ltompc_handle h) {
+  if (!h) return fail("null handle");
+  HIPCHECK(hipSetDevice(h->device));
+  HIPCHECK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int ltompc_get_stats(ltompc_handle h, int* status, int* iters, double* kkt_error, double* objective, double* mu) {
   if (!h) return fail("null handle");
   HIPCHECK(hipSetDevice(h->device));

@@ -116,6 +116,9 @@ class BatchedMPC:
         check(lib().ltompc_slip_forces(self._h, dptr(x), x.shape[0], dptr(a), dptr(F)))
         return a, F
 
+    def synchronize(self):
+        check(lib().ltompc_synchronize(self._h))
+
     def set_profiling(self, on, only: str | None = None):
         """on: False / True (every launch).  only='eval' | 'riccati' | ...: bracket the launches of that kernel class only."""
         mode = int(bool(on))
@@ -200,3 +203,86 @@ class BatchedMPC:
         if x0.shape[0] != self.B:
             raise ValueError(f"expected {self.B} states of dimension {NX}, got array of shape {x0.shape}")
         return x0
+
+
+class SplitMPC:
+    """The batch as `n_parts` handles of batch / n_parts instances, each on its own HIP stream and driven by its own host thread
+    (ctypes releases the GIL during a call).  Instances are independent NLPs, so the parts need not tick together: while one
+    part is in the narrow tail of its tick - the 1 % of its instances that need 2 - 10 times the iterations of the rest, a chain
+    of one-wavefront launches on an otherwise idle chip - the other part's full-width launches fill the GPU.  Results are the
+    single handle's, bit for bit (an instance's result does not depend on the batch it is solved in); 8192 instances at N = 40:
+    +10 % solves/s with two parts, three or more lose (narrow launches queue behind the other parts' full-width wavefronts).
+
+    The device-pointer interface of BatchedMPC for contiguous row blocks: part p owns rows [lo_p, hi_p) of every (B, .) array."""
+
+    def __init__(self, tables: TrackTables, n_horizon: int = 10, batch: int = 1, n_parts: int = 2, params: Params | None = None,
+                 options: Options | None = None, device: int = 0):
+        from concurrent.futures import ThreadPoolExecutor
+        self.N, self.B, self.n_parts = int(n_horizon), int(batch), int(n_parts)
+        base, rem = divmod(self.B, self.n_parts)
+        self.bounds = []
+        lo = 0
+        for p in range(self.n_parts):
+            hi = lo + base + (1 if p < rem else 0)
+            self.bounds.append((lo, hi)); lo = hi
+        self.parts = [BatchedMPC(tables, n_horizon, hi - lo, params=params, options=options, device=device) for lo, hi in self.bounds]
+        self.options, self.params = self.parts[0].options, self.parts[0].params
+        self._pool = ThreadPoolExecutor(max_workers=self.n_parts)
+
+    def close(self):
+        for p in self.parts:
+            p.close()
+        self._pool.shutdown(wait=True)
+
+    def _each(self, fn):
+        """fn(part, lo, hi) on every part, each in its own host thread; returns the results in part order."""
+        futs = [self._pool.submit(fn, p, lo, hi) for p, (lo, hi) in zip(self.parts, self.bounds)]
+        return [f.result() for f in futs]
+
+    def set_initial_guess_dev(self, x0_ptr: int):
+        self._each(lambda p, lo, hi: (p.set_initial_guess_dev(x0_ptr + 8 * NX * lo), p.synchronize()))
+
+    def make_step_dev(self, x0_ptr: int, u0_ptr: int):
+        self._each(lambda p, lo, hi: p.make_step_dev(x0_ptr + 8 * NX * lo, u0_ptr + 8 * NU * lo))
+
+    def run_ticks(self, x_ptr: int, u_ptr: int, xn_ptr: int, n_ticks: int, n_sub: int = 400, after_tick=None):
+        """n_ticks of the closed loop [make_step; plant step] for every part at its own pace: x (B, 8) and xn (B, 8) are swapped
+        after every tick (the states end in x if n_ticks is even, else in xn), u (B, 2) holds the last controls.
+        after_tick(part_index, tick) runs in the part's thread after each of its ticks.  Returns when all parts are done."""
+        def body(p, lo, hi):
+            a, b = x_ptr + 8 * NX * lo, xn_ptr + 8 * NX * lo
+            for t in range(n_ticks):
+                p.make_step_dev(a, u_ptr + 8 * NU * lo)
+                p.plant_step_dev(a, u_ptr + 8 * NU * lo, b, n_sub)
+                a, b = b, a
+                if after_tick is not None:
+                    after_tick(self.parts.index(p), t)
+            p.synchronize()
+        self._each(body)
+
+    def synchronize(self):
+        for p in self.parts:
+            p.synchronize()
+
+    def set_poll_every(self, n: int):
+        for p in self.parts:
+            p.set_poll_every(n)
+
+    def set_profiling(self, on, only: str | None = None):
+        for p in self.parts:
+            p.set_profiling(on, only)
+
+    def status_counts(self):
+        r = [p.status_counts() for p in self.parts]
+        return sum(c for c, _ in r), sum(s for _, s in r)
+
+    def solver_status_counts(self):
+        return sum(p.solver_status_counts() for p in self.parts)
+
+    def stats(self):
+        r = [p.stats() for p in self.parts]
+        return {k: np.concatenate([q[k] for q in r]) for k in r[0]}
+
+    def iterate(self):
+        r = [p.iterate() for p in self.parts]
+        return {k: np.concatenate([q[k] for q in r]) for k in r[0]}

@@ -2,11 +2,11 @@
 import sys, os, time, threading, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import ltompc
 T = ltompc.build_tables()
-B, N, K, Wm = 8192, 40, 5, 2
+B, N, K, Wm = 8192, 40, 16, 5
 dev = torch.device("cuda", 0)
 x0_all = ltompc.sample_x0(T, B)
 def run(S, tuned=False, prio=False):
-    o = ltompc.default_options(); o.max_iter = 150
+    o = ltompc.default_options()
     if tuned: o.warm_shift, o.mu_init_warm = 1, 1e-3
     n = B // S
     hs = []

@@ -901,6 +901,39 @@ def test_node0_rule_on_gpu(pkg, tables, orc, oracle, gpu_lib):
     m.close()
 
 
+def test_split_handles_reproduce_the_single_handle(pkg, tables, gpu_lib):
+    """SplitMPC (bench.py's default on one GPU: the batch as two handles on two streams and host threads, each ticking at its own
+    pace) returns what one handle returns, bit for bit: controls after every tick, statuses, iteration counts, iterates."""
+    import torch
+    B, N, K = 1500, 20, 4
+    dev = torch.device("cuda", 0)
+    x0 = pkg.sample_x0(tables, B, seed=77)
+    one = pkg.BatchedMPC(tables, N, B)
+    two = pkg.SplitMPC(tables, N, B, n_parts=2)
+    assert two.bounds == [(0, 750), (750, 1500)]
+    xa, xb = torch.from_numpy(x0).to(dev), torch.from_numpy(x0).to(dev)
+    xan, xbn = torch.empty_like(xa), torch.empty_like(xb)
+    ua, ub = torch.zeros(B, 2, dtype=torch.float64, device=dev), torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize(dev)
+    one.set_initial_guess_dev(xa.data_ptr()); two.set_initial_guess_dev(xb.data_ptr())
+    for _ in range(K):
+        one.make_step_dev(xa.data_ptr(), ua.data_ptr())
+        one.plant_step_dev(xa.data_ptr(), ua.data_ptr(), xan.data_ptr(), 100)
+        xa, xan = xan, xa
+    one.synchronize()
+    two.run_ticks(xb.data_ptr(), ub.data_ptr(), xbn.data_ptr(), K, 100)   # K even: the states end in xb
+    torch.cuda.synchronize(dev)
+    assert torch.equal(ua, ub) and torch.equal(xa, xb)
+    sa, sb = one.stats(), two.stats()
+    for k in ("status", "iters", "kkt", "n_resto", "n_shift", "status_solver"):
+        assert np.array_equal(sa[k], sb[k]), k
+    ia, ib = one.iterate(), two.iterate()
+    assert all(np.array_equal(ia[k], ib[k]) for k in ia)
+    ca, cb = one.status_counts(), two.status_counts()
+    assert np.array_equal(ca[0], cb[0]) and ca[1] == cb[1] and np.array_equal(one.solver_status_counts(), two.solver_status_counts())
+    one.close(); two.close()
+
+
 def test_eight_shards_of_1024_reproduce_the_8192_batch(pkg, tables, gpu_lib):
     """BASELINE config 4's per-GPU shard: 8 handles of 1024 instances (what 8 ranks hold, lap-time-optimization_amd/sharding.py)
     reproduce the one 8192-instance batch bit for bit over a cold and two warm ticks (controls, statuses, iteration counts)."""
