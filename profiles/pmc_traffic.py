@@ -12,7 +12,7 @@ factor is calibrated on k_update, a pure streaming kernel with a known byte coun
 """
 import collections, csv, glob, json, sys
 
-B, N = 8192, 40
+B, N = 8192, 40  # (B is re-derived from the widest k_update launch of the profiled run)
 UPDATE_READ, UPDATE_WRITE = 160 * 8, 80 * 8  # bytes per (instance, interval)
 
 
@@ -32,7 +32,11 @@ def per_kernel(d, counter):
 
 
 def main():
+    global B
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
+    # instances of the profiled handle: bench.py splits the batch of a GPU into handles of B / parts instances (SplitMPC); a
+    # full-width k_update launch has N * B threads
+    B = max(g for g, _ in fetch["k_update"]) // N
     res = {"batch": B, "horizon": N, "unit": "bytes per full-width launch (grid = the whole batch)", "kernels": {}}
     full = {}
     for k in fetch:
