@@ -546,6 +546,23 @@ def main():
             extras[label] = {"options": note, "converged_solves_per_s": conv / tt, "ms_per_step": 1e3 * tt / args.steps,
                              "converged_frac_last_tick": float(c[0] + c[1]) / B, "ip_iters_mean_last_tick": isum / B,
                              "ip_iterations_launched_per_tick": launched}
+            if label == "single_handle" and not args.no_profile:
+                # one more tick with every launch bracketed: the kernel classes at FULL width (all B instances in the launch) with
+                # nothing else on the GPU - the kernels' own efficiency, where the timed region's launches share the chip with the
+                # other handle's kernels
+                mt.set_profiling(True)
+                mt.make_step_dev(xt.data_ptr(), ut.data_ptr())
+                torch.cuda.synchronize(dev)
+                wk, ww, wms = mt.launch_log()
+                mt.set_profiling(False)
+                fwc, names1 = {}, list(mt.timing()["ms"].keys())
+                for ci, cname in enumerate(names1):
+                    s3 = (wk == ci) & (ww == B)
+                    if s3.any() and BYTES_BY_KERNEL.get(cname, 0) > 0:
+                        t_ms, by = float(wms[s3].mean()), B * N * BYTES_BY_KERNEL[cname]
+                        fwc[KERNEL_OF_CLASS[cname]] = {"launches": int(s3.sum()), "avg_launch_ms": round(t_ms, 4), "algorithmic_bytes_per_launch": by,
+                                                       "achieved": round(by / (t_ms * 1e-3) / 1e9, 1), "frac": round(by / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                extras[label]["full_width_by_class"] = fwc
             mt.close()
         # the same K ticks per instance as a closed-loop ROLLOUT with free-running instances (ltompc_rollout_dev: converged
         # instances start their next tick inside the running batch; bit-identical controls, tests/test_gpu_parity.py)
