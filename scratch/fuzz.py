@@ -11,12 +11,17 @@ cases = [
     dict(B=2000, N=12, warm_shift=1, mu_init_warm=1e-3), dict(B=1111, N=33, warm_reset_on_fail=0),
     dict(B=520, N=60), dict(B=900, N=8, n_linesearch=1), dict(B=900, N=8, n_linesearch=4, stall_iter=5),
     dict(B=4100, N=10, max_iter=60),
+    # round 3: the recovery steps and their options
+    dict(B=1300, N=40), dict(B=800, N=40, soft_rho=1e5), dict(B=600, N=20, resto_rho=1e4, resto_rho_max=1e6, resto_rho_factor=10.0),
+    dict(B=900, N=30, infeasible_sticky=0, resto_shift_retry=0), dict(B=900, N=30, dual_inf_max=0.0, max_mu_stay=30),
+    dict(B=700, N=25, node0_check=0, resto_sticky=2), dict(B=513, N=40, warm_shift=1, mu_init_warm=1e-3, warm_fallback_iter=6),
 ]
 bad = 0
+TICKS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for c in cases:
     c = dict(c); B, N = c.pop("B"), c.pop("N")
     o, oo = ltompc.default_options(), orc.default_options()
-    o.max_iter = oo.max_iter = 120
+    o.max_iter = oo.max_iter = 200
     for k, v in c.items():
         setattr(o, k, v)
         if k != "latency_mode": setattr(oo, k, v)
@@ -27,7 +32,7 @@ for c in cases:
     O = orc.Oracle(T.packed(), options=oo)
     x, ref, up = x0.copy(), None, np.zeros((len(sel), 2))
     line = f"B={B:5d} N={N:3d} {c}:"
-    for tick in range(3):
+    for tick in range(TICKS):
         u0 = m.make_step(x)
         ref = O.solve(x[sel], N, uprev=up, warm=ref, nthreads=8, prev_status=None if ref is None else ref["status"])
         both = (m.status[sel] == 0) & (ref["status"] == 0)
