@@ -101,8 +101,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8192, help="MPC instances per GPU")
     ap.add_argument("--parts", type=int, default=0, help="handles the batch of a GPU is split into, each on its own HIP stream and host thread, ticking at "
-                    "its own pace (SplitMPC: one part's narrow tail overlaps the other's full-width launches; results bit-identical to one "
-                    "handle).  0 = 2 on one GPU, 1 with several GPUs (the per-tick RCCL gather of the controls needs the whole rank's tick)")
+                    "its own pace (SplitMPC: one part's narrow tail overlaps the others' full-width launches; results bit-identical to one "
+                    "handle).  0 = 4 for a GPU with 4096 instances or more, else 1")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances in TOTAL, sharded over the GPUs in contiguous "
                     "blocks (BASELINE config 4: 8192); 0 = weak scaling with --batch instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
@@ -238,10 +238,8 @@ def main():
     B, n_total = hi - lo, (args.total_batch if args.total_batch else args.batch * world)
     opts = ltompc.default_options()
     opts.max_iter, opts.soft_rho, opts.resto_sticky = args.max_iter, args.soft_rho, args.resto_sticky
-    n_parts = args.parts if args.parts > 0 else (2 if world == 1 else 1)
+    n_parts = args.parts if args.parts > 0 else (4 if B >= 4096 else 1)
     split = n_parts > 1
-    if split and world > 1:
-        raise SystemExit("bench.py: --parts > 1 is for one GPU (with several ranks the controls are gathered every tick, which needs the rank's whole tick)")
     stream = torch.cuda.current_stream(dev)
     if split:
         mpc = ltompc.SplitMPC(tables, n_horizon=N, batch=B, n_parts=n_parts, options=opts, device=local_rank)  # (each part on its own stream)
@@ -257,14 +255,75 @@ def main():
     x = torch.from_numpy(np.ascontiguousarray(x0_host)).to(dev)
     xn = torch.empty_like(x)
     u = torch.zeros(B, 2, dtype=torch.float64, device=dev)
+    u_ring = [u, torch.zeros_like(u)]  # split handles on several ranks: tick t's controls go to u_ring[t % 2] (see run_split)
 
     gather_ev = []  # (start, end) events around the gather of every timed tick
 
-    def run_split(k, after_tick=None):
-        """k ticks of every part at its own pace (SplitMPC.run_ticks); the states end in x"""
+    def run_split(k, after_tick=None, timed=False):
+        """k ticks of every part at its own pace (SplitMPC.run_ticks); the states end in x.
+        With several ranks the controls of the whole batch are still gathered on every rank once per tick (north_star: results
+        gathered over RCCL / xGMI), by THIS thread, so that every rank issues the same sequence of collectives: the parts write
+        tick t's controls to u_ring[t % 2]; when all parts of the rank have finished tick t its block is gathered, and a part starts
+        tick t + 2 (which writes the same buffer again) only after that gather has completed - the parts run at most one tick
+        ahead of the gather, and nothing of a tick's data path waits for another rank."""
         nonlocal x, xn
         torch.cuda.synchronize(dev)
-        mpc.run_ticks(x.data_ptr(), u.data_ptr(), xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after_tick)
+        if world == 1:
+            mpc.run_ticks(x.data_ptr(), u.data_ptr(), xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after_tick)
+        else:
+            import threading
+            cond = threading.Condition()
+            done, gathered, failure = [0] * n_parts, [-1], []
+
+            def before(pi, t):
+                with cond:
+                    cond.wait_for(lambda: gathered[0] >= t - 2 or failure)
+                if failure:
+                    raise RuntimeError("the gather thread failed")
+
+            def after(pi, t):
+                if after_tick is not None:
+                    after_tick(pi, t)
+                mpc.parts[pi].synchronize()  # tick t's controls are in u_ring[t % 2]
+                with cond:
+                    done[pi] = t + 1
+                    cond.notify_all()
+
+            def ticks():
+                try:
+                    mpc.run_ticks(x.data_ptr(), [q.data_ptr() for q in u_ring], xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after, before_tick=before)
+                except BaseException as e:  # (a part failed: let the gather loop below end instead of waiting for ever)
+                    with cond:
+                        failure.append(e)
+                        cond.notify_all()
+
+            th = threading.Thread(target=ticks)
+            th.start()
+            try:
+                for t in range(k):
+                    with cond:
+                        cond.wait_for(lambda: min(done) >= t + 1 or failure)
+                    if failure:
+                        break
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    shard.gather_rows(u_ring[t % 2], n_total, rank, world)
+                    e1.record(stream)
+                    stream.synchronize()
+                    if timed:
+                        gather_ev.append((e0, e1))
+                    with cond:
+                        gathered[0] = t
+                        cond.notify_all()
+            except BaseException as e:
+                with cond:
+                    failure.append(e)
+                    cond.notify_all()
+                raise
+            finally:
+                th.join()
+            if failure:
+                raise failure[0]
         if k % 2:
             x, xn = xn, x
 
@@ -326,7 +385,7 @@ def main():
             q = mpc.parts[pi]
             c, isum = q.status_counts()
             rec[pi][t] = (c, isum, q.solver_status_counts(), q.timing()["ip_iterations"], q.active_history() if not args.no_profile else None)
-        run_split(args.steps, after_tick=after)
+        run_split(args.steps, after_tick=after, timed=True)
         for t in range(args.steps):
             per_tick_counts.append(sum(rec[pi][t][0] for pi in range(n_parts)))
             per_tick_itersum.append(sum(rec[pi][t][1] for pi in range(n_parts)))

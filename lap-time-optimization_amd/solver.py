@@ -211,11 +211,12 @@ class SplitMPC:
     part is in the narrow tail of its tick - the 1 % of its instances that need 2 - 10 times the iterations of the rest, a chain
     of one-wavefront launches on an otherwise idle chip - the other part's full-width launches fill the GPU.  Results are the
     single handle's, bit for bit (an instance's result does not depend on the batch it is solved in); 8192 instances at N = 40:
-    +10 % solves/s with two parts, three or more lose (narrow launches queue behind the other parts' full-width wavefronts).
+    134 k solves/s with two parts and 142 k with four against 124 k (five or more lose: the HIP runtime serves a process's streams
+    with four hardware queues, and a narrow launch then waits behind another part's full-width launches in the same queue).
 
     The device-pointer interface of BatchedMPC for contiguous row blocks: part p owns rows [lo_p, hi_p) of every (B, .) array."""
 
-    def __init__(self, tables: TrackTables, n_horizon: int = 10, batch: int = 1, n_parts: int = 2, params: Params | None = None,
+    def __init__(self, tables: TrackTables, n_horizon: int = 10, batch: int = 1, n_parts: int = 4, params: Params | None = None,
                  options: Options | None = None, device: int = 0):
         from concurrent.futures import ThreadPoolExecutor
         self.N, self.B, self.n_parts = int(n_horizon), int(batch), int(n_parts)
@@ -245,18 +246,26 @@ class SplitMPC:
     def make_step_dev(self, x0_ptr: int, u0_ptr: int):
         self._each(lambda p, lo, hi: p.make_step_dev(x0_ptr + 8 * NX * lo, u0_ptr + 8 * NU * lo))
 
-    def run_ticks(self, x_ptr: int, u_ptr: int, xn_ptr: int, n_ticks: int, n_sub: int = 400, after_tick=None):
+    def run_ticks(self, x_ptr: int, u_ptr, xn_ptr: int, n_ticks: int, n_sub: int = 400, after_tick=None, before_tick=None):
         """n_ticks of the closed loop [make_step; plant step] for every part at its own pace: x (B, 8) and xn (B, 8) are swapped
-        after every tick (the states end in x if n_ticks is even, else in xn), u (B, 2) holds the last controls.
-        after_tick(part_index, tick) runs in the part's thread after each of its ticks.  Returns when all parts are done."""
+        after every tick (the states end in x if n_ticks is even, else in xn), u (B, 2) holds the last controls.  u_ptr may be a
+        sequence of pointers: tick t then writes its controls to u_ptr[t % len(u_ptr)] (a ring: somebody else - a gather over the
+        ranks, a logger - reads the controls of tick t while the parts are one tick further).
+        before_tick(part_index, tick) / after_tick(part_index, tick) run in the part's thread around each of its ticks (before_tick
+        may block: that is how a consumer of the ring holds a part back).  Returns when all parts are done."""
+        ring = [int(u_ptr)] if isinstance(u_ptr, int) else [int(q) for q in u_ptr]
         def body(p, lo, hi):
             a, b = x_ptr + 8 * NX * lo, xn_ptr + 8 * NX * lo
+            pi = self.parts.index(p)
             for t in range(n_ticks):
-                p.make_step_dev(a, u_ptr + 8 * NU * lo)
-                p.plant_step_dev(a, u_ptr + 8 * NU * lo, b, n_sub)
+                if before_tick is not None:
+                    before_tick(pi, t)
+                u = ring[t % len(ring)] + 8 * NU * lo
+                p.make_step_dev(a, u)
+                p.plant_step_dev(a, u, b, n_sub)
                 a, b = b, a
                 if after_tick is not None:
-                    after_tick(self.parts.index(p), t)
+                    after_tick(pi, t)
             p.synchronize()
         self._each(body)
 
