@@ -272,58 +272,38 @@ def main():
             mpc.run_ticks(x.data_ptr(), u.data_ptr(), xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after_tick)
         else:
             import threading
-            cond = threading.Condition()
-            done, gathered, failure = [0] * n_parts, [-1], []
-
-            def before(pi, t):
-                with cond:
-                    cond.wait_for(lambda: gathered[0] >= t - 2 or failure)
-                if failure:
-                    raise RuntimeError("the gather thread failed")
+            pipe = shard.TickPipeline(n_parts, depth=len(u_ring))
 
             def after(pi, t):
                 if after_tick is not None:
                     after_tick(pi, t)
                 mpc.parts[pi].synchronize()  # tick t's controls are in u_ring[t % 2]
-                with cond:
-                    done[pi] = t + 1
-                    cond.notify_all()
+                pipe.after_tick(pi, t)
 
             def ticks():
                 try:
-                    mpc.run_ticks(x.data_ptr(), [q.data_ptr() for q in u_ring], xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after, before_tick=before)
+                    mpc.run_ticks(x.data_ptr(), [q.data_ptr() for q in u_ring], xn.data_ptr(), k, PLANT_SUBSTEPS, after_tick=after,
+                                  before_tick=pipe.before_tick)
                 except BaseException as e:  # (a part failed: let the gather loop below end instead of waiting for ever)
-                    with cond:
-                        failure.append(e)
-                        cond.notify_all()
+                    pipe.fail(e)
+
+            def gather(t):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                shard.gather_rows(u_ring[t % len(u_ring)], n_total, rank, world)
+                e1.record(stream)
+                stream.synchronize()  # the slot may be written again once this returns
+                if timed:
+                    gather_ev.append((e0, e1))
 
             th = threading.Thread(target=ticks)
             th.start()
             try:
-                for t in range(k):
-                    with cond:
-                        cond.wait_for(lambda: min(done) >= t + 1 or failure)
-                    if failure:
-                        break
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(stream)
-                    shard.gather_rows(u_ring[t % 2], n_total, rank, world)
-                    e1.record(stream)
-                    stream.synchronize()
-                    if timed:
-                        gather_ev.append((e0, e1))
-                    with cond:
-                        gathered[0] = t
-                        cond.notify_all()
-            except BaseException as e:
-                with cond:
-                    failure.append(e)
-                    cond.notify_all()
-                raise
+                pipe.consume(k, gather)
             finally:
                 th.join()
-            if failure:
-                raise failure[0]
+            if pipe.failure is not None:
+                raise pipe.failure
         if k % 2:
             x, xn = xn, x
 
