@@ -51,6 +51,14 @@ def lib() -> C.CDLL:
             raise LtompcError(
                 f"{LIB} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own HIP runtime; libltompc.so links the system one.  In one process the first one loaded
+        # serves both, and it has to be torch's: with the system runtime initialised first (a handle created before `import torch`)
+        # torch finds no devices ("No HIP GPUs are available", measured on the MI355X box).  So torch is imported here when it is
+        # installed; without torch the library runs on the system runtime alone.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB)
         L.ltompc_last_error.restype = C.c_char_p
         L.ltompc_version.restype = C.c_char_p

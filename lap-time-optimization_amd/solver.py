@@ -269,6 +269,15 @@ class SplitMPC:
             p.synchronize()
         self._each(body)
 
+    def rollout_dev(self, x_ptr: int, n_ticks: int, n_sub: int = 400, u_log_ptr: int = 0, status_log_ptr: int = 0, iters_log_ptr: int = 0):
+        """BatchedMPC.rollout_dev on every part at once (the logs are (B, n_ticks, .) arrays: part p fills its rows).  Returns the
+        longest chain of passes over the parts and the launches of all of them."""
+        def body(p, lo, hi):
+            return p.rollout_dev(x_ptr + 8 * NX * lo, n_ticks, n_sub, u_log_ptr + 8 * NU * n_ticks * lo if u_log_ptr else 0,
+                                 status_log_ptr + 4 * n_ticks * lo if status_log_ptr else 0, iters_log_ptr + 4 * n_ticks * lo if iters_log_ptr else 0)
+        r = self._each(body)
+        return dict(iterations=max(q["iterations"] for q in r), launches=sum(q["launches"] for q in r), per_part=r)
+
     def synchronize(self):
         for p in self.parts:
             p.synchronize()

@@ -931,7 +931,31 @@ def test_split_handles_reproduce_the_single_handle(pkg, tables, gpu_lib):
     assert all(np.array_equal(ia[k], ib[k]) for k in ia)
     ca, cb = one.status_counts(), two.status_counts()
     assert np.array_equal(ca[0], cb[0]) and ca[1] == cb[1] and np.array_equal(one.solver_status_counts(), two.solver_status_counts())
-    one.close(); two.close()
+    # three uneven parts, the controls of tick t written to slot t % 2 of a ring (bench.py with several ranks: the per-tick gather
+    # reads a slot while the parts are one tick further), hooks around every tick; then the free-running rollout of every part
+    three = pkg.SplitMPC(tables, N, B, n_parts=3)
+    assert three.bounds == [(0, 500), (500, 1000), (1000, 1500)]
+    xc = torch.from_numpy(x0).to(dev)
+    xcn, ring = torch.empty_like(xc), [torch.zeros(B, 2, dtype=torch.float64, device=dev) for _ in range(2)]
+    torch.cuda.synchronize(dev)
+    three.set_initial_guess_dev(xc.data_ptr())
+    calls = []
+    three.run_ticks(xc.data_ptr(), [q.data_ptr() for q in ring], xcn.data_ptr(), K, 100, before_tick=lambda pi, t: calls.append(("b", pi, t)),
+                    after_tick=lambda pi, t: calls.append(("a", pi, t)))
+    torch.cuda.synchronize(dev)
+    assert torch.equal(xc, xa) and torch.equal(ring[(K - 1) % 2], ua) and not torch.equal(ring[K % 2], ua)
+    assert sorted(calls) == sorted((w, pi, t) for w in "ab" for pi in range(3) for t in range(K))
+    R = 3
+    sl1, sl3 = (torch.full((B, R), -1, dtype=torch.int32, device=dev) for _ in range(2))
+    il1, il3 = (torch.zeros(B, R, dtype=torch.int32, device=dev) for _ in range(2))
+    ul1, ul3 = (torch.zeros(B, R, 2, dtype=torch.float64, device=dev) for _ in range(2))
+    torch.cuda.synchronize(dev)
+    one.rollout_dev(xa.data_ptr(), R, 100, ul1.data_ptr(), sl1.data_ptr(), il1.data_ptr())
+    info = three.rollout_dev(xc.data_ptr(), R, 100, ul3.data_ptr(), sl3.data_ptr(), il3.data_ptr())
+    torch.cuda.synchronize(dev)
+    assert torch.equal(xa, xc) and torch.equal(ul1, ul3) and torch.equal(sl1, sl3) and torch.equal(il1, il3)
+    assert len(info["per_part"]) == 3 and info["iterations"] == max(q["iterations"] for q in info["per_part"])
+    one.close(); two.close(); three.close()
 
 
 def test_eight_shards_of_1024_reproduce_the_8192_batch(pkg, tables, gpu_lib):
