@@ -511,7 +511,9 @@ def main():
                     t_ms, by = float(wms[s3].mean()), B_acc * N * BYTES_BY_KERNEL[cname]
                     fwc[KERNEL_OF_CLASS[cname]] = {"launches": int(s3.sum()), "avg_launch_ms": round(t_ms, 4), "algorithmic_bytes_per_launch": by,
                                                    "achieved": round(by / (t_ms * 1e-3) / 1e9, 1), "frac": round(by / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-            roofline["full_width_by_class"] = fwc
+            # (split handles: these launches shared the chip with the other handles' kernels - a statement about the mix, not about
+            #  the kernels; the same table for ONE handle of all B instances with nothing beside it is added below from the side run)
+            roofline["full_width_by_class_beside_the_other_handles" if split else "full_width_by_class"] = fwc
         by_width = {}
         for w in sorted(set(int(v) for v in width[sel]), reverse=True)[:12]:
             s2 = sel & (width == w)
@@ -631,6 +633,9 @@ def main():
         mr.close()
         if split:  # the same workload on ONE handle of all B instances (what `value` was in rounds 1 and 2)
             side_run(opts, "single_handle", {"parts": 1})
+            if roofline is not None and "full_width_by_class" in extras.get("single_handle", {}):
+                roofline["full_width_by_class"] = extras["single_handle"]["full_width_by_class"]
+                roofline["full_width_by_class_from"] = f"extras.single_handle: one handle of all {B} instances, nothing running beside its launches"
         # the same workload at round 1's iteration budget (150 instead of the reference's 1000)
         o150 = ltompc.default_options(); o150.max_iter, o150.soft_rho = 150, args.soft_rho
         side_run(o150, "max_iter_150", {"max_iter": 150})
