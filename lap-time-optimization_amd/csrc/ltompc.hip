@@ -88,6 +88,7 @@ struct ltompc_solver {
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int sweeps_width = 16;  // LTOMPC_SWEEPS_W: launches of at most this many instances repeat a failed Riccati sweep inside the launch (up to 4 attempts)
+  int ric1q_width = 64;  // LTOMPC_RIC1Q: launches of at most this many instances use the four-wavefront form of the single-instance sweep (0 = never)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 
@@ -173,8 +174,13 @@ int launch_iteration(ltompc_solver* h, Launcher& L, const Launch& la, const int 
       // fewer launches but doubles the time of every narrow launch: 193 ms vs 145 ms per tick at B = 8192
       const int max_sweeps = 1;
       if (n_launch <= h->ric1_width) {
-        L.lds = ric1_lds_bytes(N);
-        if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;  // one wavefront per instance
+        if (n_launch <= h->ric1q_width) {  // four wavefronts per instance
+          L.lds = ric1q_lds_bytes(N), L.block_threads = 256;
+          if (L.run(6, k_riccati1q, n_launch * 256, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;
+        } else {
+          L.lds = ric1_lds_bytes(N);
+          if (L.run(6, k_riccati1, n_launch * 64, h->K, h->W, la, it, n_launch <= h->sweeps_width ? 4 : 1)) return -1;  // one wavefront per instance
+        }
       } else if (L.run(1, k_riccati8, np * 8, h->K, h->W, la, it, max_sweeps)) return -1;  // 8 lanes per instance
     }
     if (riccati_only) return 0;  // (make_step's last pass: only finalises the statuses, MAX_ITER)
@@ -356,12 +362,14 @@ int ltompc_create(const ltompc_params* params, const ltompc_options* options, co
     if (npl) h->n_plant_streams = std::min((int)ltompc_solver::ROLL_PLANTS, std::max(1, std::atoi(npl)));
     const char* sw = getenv("LTOMPC_SWEEPS_W");
     if (sw) h->sweeps_width = atoi(sw);
-    // k_riccati1 stages the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
-    if (ric1_lds_bytes(n_horizon) > 150 * 1024) h->ric1_width = 0;
+    const char* rq = getenv("LTOMPC_RIC1Q");
+    if (rq) h->ric1q_width = atoi(rq);
+    // k_riccati1 / k_riccati1q stage the whole horizon of an instance in LDS (160 KiB per CU on gfx950)
+    if (std::max(ric1_lds_bytes(n_horizon), ric1q_lds_bytes(n_horizon)) > 150 * 1024) h->ric1_width = 0;
     // (the attribute belongs to the kernel, not to the handle: always the cap, so that handles with different horizons
     //  do not lower each other's limit)
-    else if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_riccati1), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 150 * 1024) != hipSuccess) {
+    else if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_riccati1), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess ||
+             hipFuncSetAttribute(reinterpret_cast<const void*>(k_riccati1q), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
       (void)hipGetLastError();
       h->ric1_width = 0;
     }

@@ -1208,12 +1208,398 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
 #undef RTOCK
 }
 
+// ---- four-wavefront form of the single-instance sweep (k_riccati1q).  In d_riccati1 every lane forms, beside its own element of
+// the 8x8 products, the row's Hxu / gx and an element of Huu / gu: ~100 fp64 operations and ~130 LDS reads per lane and stage
+// where its own element needs 18, and with one wavefront on the SIMD the stage is as long as its instruction count (~3600 cycles).
+// Here the ROLES run beside each other on four wavefronts (one per SIMD of the CU), exchanging through LDS at three workgroup
+// barriers per stage:
+//   phase A   w0 lane (i, g): P A;                  w1 lanes (i, c): P B, lanes 16 + i: P b + p
+//   phase B   w0: Hxx element;                      w1: Hxu(c, i), gx(i);      w2 lanes (c, d): Huu;      w3 lanes d: gu
+//   phase C   w0: new P element (own K from Hxu of row g);  w1: K, Pxv, p;     w2: Kv, Pvv;               w3: kff, pv
+// Every value is formed by ONE lane with the statement d_riccati1 / d_riccati8 use for it (same operands, same order), so the
+// Riccati buffer is the same, word for word (scratch/rc_cmp.py, tests: the kernel paths agree bit for bit).
+struct Ric1qLds {
+  double PA[64], PB[16], Pb[8], Hxu[16], gx[8], Huu[4], gu[2], Pn[64], Pxv[16], pp[8], Pvv[4], pv[2];
+  double mu, delta_w;
+  int go, live, again, pad_;
+};
+__host__ __device__ constexpr size_t ric1q_lds_bytes(int N) { return sizeof(double) * (size_t)N * (QP_NF + 24) + sizeof(Ric1qLds); }
+
+// Workgroup barrier for data exchanged through LDS only: waits for the wavefront's own LDS operations (lgkmcnt), NOT for its
+// outstanding global stores - __syncthreads() also drains vmcnt, and every barrier of a stage would then wait for the Riccati
+// words the stage has just stored to HBM (measured: a stage of k_riccati1q 3500 cycles with __syncthreads()).
+#define WG_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#if !defined(LTOMPC_HOST_HARNESS)
+__device__ __forceinline__ void d_riccati1q(const Consts& K, const Work& W, Ric1qLds& X, const StageLds& S, const int t, const int b,
+                                            const int active_slot, const int max_sweeps) {
+  const int N = W.N;
+  double* st = W.st;
+  int* si = W.si;
+  const ltompc_options& o = K.o;
+  const int w = t >> 6, lane = t & 63, i = lane >> 3, g = lane & 7;
+  const bool rprof = W.DBG != nullptr && blockIdx.x == 0 && t == 0;
+  long long rt0 = rprof ? clock64() : 0;
+#define RTOCK(q) if (rprof) { const long long t1 = clock64(); W.DBG[q] += (double)(t1 - rt0); rt0 = t1; }
+  // ---- head (wavefront 0) beside the staging of the instance's stage blocks in LDS (wavefronts 1 - 3)
+  bool live = false, retry = false;  // (wavefront 0, lanes g == 0)
+  double mu = 0.0;
+  double psc = 1.0, dw_last = 0.0;  // (wavefront 0: read after the head, which may change the instance's penalty)
+  int tries = 0;
+  bool numerical = false;
+  if (w == 0) {
+    const bool go = d_head8(K, W, i, b, g == 0, active_slot, live, retry, mu);
+    psc = pen_scale(STD(ST_RHO));  // penalty scale (layout.h): the regularisation schedule in its units
+    dw_last = STD(ST_DW_LAST);
+    double delta_w = STD(ST_FORCE_REG);
+    if (delta_w == 0.0 && dw_last > DW_KEEP * psc) delta_w = dw_last / 3.0;  // see DESIGN.md §3 (deviation from Algorithm IC)
+    if (retry) delta_w = STD(ST_DW_TRY), tries = STI(SI_TRIES);
+    if (t == 0) X.go = go ? 1 : 0, X.live = live ? 1 : 0, X.mu = mu, X.delta_w = delta_w;
+  } else {
+    const int ln = t - 64;  // 0 .. 191: fields ln and ln + 192 of a stage block, eight stage blocks per round (16 independent loads)
+    for (int k0 = 0; k0 < N; k0 += 8) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int kq = k0 + u < N ? k0 + u : N - 1;
+        const double* src = &PG(W.QP, 0, kq, QP_NF);
+        v[u * 2] = src[ln * 8];
+        v[u * 2 + 1] = src[(ln + 192 < QP_NF ? ln + 192 : QP_NF - 1) * 8];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (k0 + u < N) {
+          S.q[(k0 + u) * QP_NF + ln] = v[u * 2];
+          if (ln + 192 < QP_NF) S.q[(k0 + u) * QP_NF + ln + 192] = v[u * 2 + 1];
+        }
+    }
+    for (int idx = ln; idx < N * 2; idx += 192) S.u[idx] = PL(W.U, idx & 1, idx >> 1, N);
+  }
+  WG_SYNC_LDS();
+  RTOCK(0);
+  if (!X.go) return;
+  const bool live_w = X.live != 0;  // the instance has a sweep to do (head8 returns true only then: one instance per workgroup)
+  mu = X.mu;
+  const double up0 = W.uprev[b], up1 = W.uprev[(size_t)W.Bp + b];
+  const double r2[2] = {2.0 * K.p.r_du[0], 2.0 * K.p.r_du[1]};
+  // roles of wavefront 1: lanes 0 .. 15 = (row, input) pairs, lanes 16 .. 23 = rows
+  const int r1 = lane < 16 ? (lane >> 1) : (lane - 16), c1w = lane & 1;
+  const int row = w == 0 ? i : (r1 & 7);
+  RTOCK(1);
+  for (int sweep = 0;; sweep++) {
+    const double delta_w = X.delta_w;
+    bool ok = true;
+    // terminal node: P_N (as a full symmetric matrix in Pn: the row builder below then returns it unchanged), p_N, Pxv_N = 0
+    if (w == 0) {
+      const double pnn = PG(W.QP, QP_Qx + sidx(i, g), N, QP_NF) + ((i == g) ? delta_w : 0.0);
+      X.Pn[i * 8 + g] = pnn;
+      if (live_w && g <= i) PG(W.RC, RC_P + sidx(i, g), N, RC_NF) = pnn;
+    } else if (w == 1) {
+      if (lane < 16) {
+        X.Pxv[lane] = 0.0;
+        if (live_w) PG(W.RC, RC_Pxv + lane, N, RC_NF) = 0.0;
+      } else if (lane < 24) {
+        const double ppn = PG(W.QP, QP_qx0 + r1, N, QP_NF) + mu * PG(W.QP, QP_qx1 + r1, N, QP_NF);
+        X.pp[r1] = ppn;
+        if (live_w) PG(W.RC, RC_pp + r1, N, RC_NF) = ppn;
+      }
+    } else if (w == 2) {
+      if (lane < 4) X.Pvv[lane] = 0.0;
+    } else {
+      if (lane < 2) X.pv[lane] = 0.0;
+    }
+    WG_SYNC_LDS();
+    double pn_prev = 0.0;
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; k--) {
+      const double* qk = S.q + k * QP_NF;
+      const int km = k > 0 ? k - 1 : 0;
+      const double wn = k > 0 ? 1.0 : 0.0;
+      // ---- phase A: row `row` of the symmetrised P of stage k + 1, then P A / P B / P b + p
+      double hxx = 0.0;
+      if (w == 0 || (w == 1 && lane < 24)) {
+        double Pr[8], Pc[8], Prow[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) Pr[j] = X.Pn[row * 8 + j], Pc[j] = X.Pn[j * 8 + row];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const double sy = 0.5 * (Pr[j] + Pc[j]);
+          Prow[j] = (j == row) ? Pr[j] : sy;
+        }
+        if (w == 0) {
+          if (live_w && g <= i && k + 1 < N) {  // the element of stage k + 1 this lane formed in its phase C (d_riccati1: psym)
+            const double Pt = X.Pn[g * 8 + i];
+            const double sy_own = 0.5 * (pn_prev + Pt);
+            PG(W.RC, RC_P + sidx(i, g), k + 1, RC_NF) = (g == i) ? pn_prev : sy_own;
+          }
+          double Ag[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Ag[l] = qk[QP_A + l * 8 + g];
+          double pa = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) pa += Prow[l] * Ag[l];
+          X.PA[i * 8 + g] = pa;
+          const double qa = qk[QP_Q + sidx(i, g)], qb = qk[QP_Qx + sidx(i, g)];
+          hxx = qa + ((i == g) ? delta_w : 0.0) + wn * qb;
+        } else if (lane < 16) {
+          double Bg[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Bg[l] = qk[QP_B + l * 2 + c1w];
+          double pb = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l++) pb += Prow[l] * Bg[l];
+          X.PB[r1 * 2 + c1w] = pb;
+        } else {
+          double bl[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) bl[l] = qk[QP_b + l];
+          double Pbi = X.pp[r1];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Pbi += Prow[l] * bl[l];
+          X.Pb[r1] = Pbi;
+        }
+      }
+      WG_SYNC_LDS();
+      // ---- phase B: Hxx, Hxu, gx, Huu, gu - one element per lane
+      if (w == 0) {
+        double Ai[8], PAg[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) Ai[l] = qk[QP_A + l * 8 + i], PAg[l] = X.PA[l * 8 + g];
+#pragma unroll
+        for (int l = 0; l < 8; l++) {
+          double ali = Ai[l];
+          hxx += ali * PAg[l];
+        }
+      } else if (w == 1) {
+        if (lane < 16) {
+          double Ai[8], PAi[8], Bc[8], Xc[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Ai[l] = qk[QP_A + l * 8 + r1], PAi[l] = X.PA[l * 8 + r1], Bc[l] = qk[QP_B + l * 2 + c1w], Xc[l] = X.Pxv[l * 2 + c1w];
+          double h = qk[QP_S + c1w * 8 + r1];
+#pragma unroll
+          for (int l = 0; l < 8; l++) {
+            double ali = Ai[l];
+            double pali = PAi[l];
+            h += Bc[l] * pali + Xc[l] * ali;
+          }
+          X.Hxu[c1w * 8 + r1] = h;
+        } else if (lane < 24) {
+          double Ai[8], Pbv[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Ai[l] = qk[QP_A + l * 8 + r1], Pbv[l] = X.Pb[l];
+          const double q0 = qk[QP_q0 + r1], q1 = qk[QP_q1 + r1], x0 = qk[QP_qx0 + r1], x1 = qk[QP_qx1 + r1];
+          double gx = q0 + mu * q1 + wn * (x0 + mu * x1);
+#pragma unroll
+          for (int l = 0; l < 8; l++) {
+            double ali = Ai[l];
+            gx += ali * Pbv[l];
+          }
+          X.gx[r1] = gx;
+        }
+      } else if (w == 2) {
+        if (lane < 4) {
+          const int c1 = lane >> 1, d1 = lane & 1;
+          double Bc[8], PBd[8], Xd[8], Xc[8], Bg[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++)
+            Bc[l] = qk[QP_B + l * 2 + c1], PBd[l] = X.PB[l * 2 + d1], Xd[l] = X.Pxv[l * 2 + d1], Xc[l] = X.Pxv[l * 2 + c1], Bg[l] = qk[QP_B + l * 2 + d1];
+          const double Rm[3] = {qk[QP_R + 0], qk[QP_R + 1], qk[QP_R + 2]};
+          const double rm = (c1 && d1) ? Rm[2] : ((c1 || d1) ? Rm[1] : Rm[0]);  // Rm[sidx(c, d)]
+          const double pvv = X.Pvv[c1 * 2 + d1];
+          double s = rm + pvv;
+#pragma unroll
+          for (int l = 0; l < 8; l++) s += Bc[l] * PBd[l] + Bc[l] * Xd[l] + Xc[l] * Bg[l];
+          const double r2c = c1 ? r2[1] : r2[0];
+          double heH = s;
+          if (c1 == d1) heH += r2c + delta_w;
+          X.Huu[lane] = heH;
+        }
+      } else {
+        if (lane < 2) {
+          const int d1 = lane;
+          double Bg[8], Pbv[8], Xd[8], bl[8];
+#pragma unroll
+          for (int l = 0; l < 8; l++) Bg[l] = qk[QP_B + l * 2 + d1], Pbv[l] = X.Pb[l], Xd[l] = X.Pxv[l * 2 + d1], bl[l] = qk[QP_b + l];
+          const double rr = qk[QP_r0 + d1] + mu * qk[QP_r1 + d1];
+          const double uk = S.u[k * 2 + d1], vk = k > 0 ? S.u[km * 2 + d1] : (d1 ? up1 : up0);
+          const double r2d = d1 ? r2[1] : r2[0];
+          double sg = rr + r2d * (uk - vk) + X.pv[d1];
+#pragma unroll
+          for (int l = 0; l < 8; l++) sg += Bg[l] * Pbv[l] + Xd[l] * bl[l];
+          X.gu[d1] = sg;
+        }
+      }
+      WG_SYNC_LDS();
+      // ---- phase C: gains and cost-to-go
+      {
+        double Huu[4] = {X.Huu[0], X.Huu[1], X.Huu[2], X.Huu[3]}, gu[2] = {X.gu[0], X.gu[1]};
+        double det = Huu[0] * Huu[3] - Huu[1] * Huu[2];
+        const bool bad = !(Huu[0] > 0.0) || !(det > 1e-14 * Huu[0] * Huu[3]) || !isfinite(det);
+        if (bad) ok = false;
+        if (bad) det = 1.0, Huu[0] = Huu[3] = 1.0, Huu[1] = Huu[2] = 0.0;
+        const double idet = 1.0 / det;  // one division per stage instead of four (same expression in the Riccati kernels)
+        const double Hi[4] = {Huu[3] * idet, -Huu[1] * idet, -Huu[2] * idet, Huu[0] * idet};
+        if (w == 0) {
+          const double Hxi[2] = {X.Hxu[i], X.Hxu[8 + i]}, Hxu[2] = {X.Hxu[g], X.Hxu[8 + g]};
+          double Kc[2];  // K[c][g]: the statement of the row-g lanes of d_riccati1
+#pragma unroll
+          for (int c = 0; c < 2; c++) Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);
+          const double pn = hxx + Hxi[0] * Kc[0] + Hxi[1] * Kc[1];
+          X.Pn[i * 8 + g] = pn;
+          pn_prev = pn;
+        } else if (w == 1) {
+          if (lane < 24) {
+            const double Hxu[2] = {X.Hxu[r1], X.Hxu[8 + r1]};
+            double Kc[2], Kv[4], kff[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+              Kc[c] = -(Hi[c * 2 + 0] * Hxu[0] + Hi[c * 2 + 1] * Hxu[1]);  // K[c][i]
+              Kv[c * 2 + 0] = Hi[c * 2 + 0] * r2[0], Kv[c * 2 + 1] = Hi[c * 2 + 1] * r2[1];
+              kff[c] = -(Hi[c * 2 + 0] * gu[0] + Hi[c * 2 + 1] * gu[1]);
+            }
+            if (lane < 16) {
+              double pxv[2];
+              pxv[0] = Hxu[0] * Kv[0] + Hxu[1] * Kv[2], pxv[1] = Hxu[0] * Kv[1] + Hxu[1] * Kv[3];
+              const double pxv_own = c1w ? pxv[1] : pxv[0], K_own = c1w ? Kc[1] : Kc[0];
+              X.Pxv[r1 * 2 + c1w] = pxv_own;
+              S.kk[k * 22 + RC_K + c1w * 8 + r1] = K_own;  // the gains stay in LDS for the forward rollout (kk offsets = RC fields)
+              if (live_w) {
+                PG(W.RC, RC_K + c1w * 8 + r1, k, RC_NF) = K_own;
+                if (k > 0) PG(W.RC, RC_Pxv + r1 * 2 + c1w, k, RC_NF) = pxv_own;
+              }
+            } else {
+              const double ppi = X.gx[r1] + Hxu[0] * kff[0] + Hxu[1] * kff[1];
+              X.pp[r1] = ppi;
+              if (live_w && k > 0) PG(W.RC, RC_pp + r1, k, RC_NF) = ppi;
+            }
+          }
+        } else if (w == 2) {
+          if (lane < 4) {
+            const int c = lane >> 1, d = lane & 1;
+            double Kv[4];
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) Kv[cc * 2 + 0] = Hi[cc * 2 + 0] * r2[0], Kv[cc * 2 + 1] = Hi[cc * 2 + 1] * r2[1];
+            const double Kv_own = lane == 0 ? Kv[0] : (lane == 1 ? Kv[1] : (lane == 2 ? Kv[2] : Kv[3]));
+            const double r2c = c ? r2[1] : r2[0];
+            X.Pvv[lane] = ((c == d) ? r2c : 0.0) - r2c * Kv_own;
+            S.kk[k * 22 + RC_Kv + lane] = Kv_own;
+            if (live_w) PG(W.RC, RC_Kv + lane, k, RC_NF) = Kv_own;
+          }
+        } else {
+          if (lane < 2) {
+            const int c = lane;
+            double kff[2];
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) kff[cc] = -(Hi[cc * 2 + 0] * gu[0] + Hi[cc * 2 + 1] * gu[1]);
+            const double kf = c ? kff[1] : kff[0];
+            const double uk = S.u[k * 2 + c], vk = k > 0 ? S.u[km * 2 + c] : (c ? up1 : up0);
+            const double r2c = c ? r2[1] : r2[0];
+            const double gv = -r2c * (uk - vk);
+            X.pv[c] = gv - r2c * kf;
+            S.kk[k * 22 + RC_kff + c] = kf;
+            if (live_w) PG(W.RC, RC_kff + c, k, RC_NF) = kf;
+          }
+        }
+      }
+      WG_SYNC_LDS();
+    }
+    // inertia correction schedule (Waechter & Biegler 2006, Algorithm IC): thread 0 keeps the instance's books
+    if (t == 0) {
+      double dw = delta_w;
+      const bool failed = live && !ok;
+      if (failed) {
+        if (dw == 0.0) dw = dw_last == 0.0 ? o.delta_w_first * psc : fmax(1e-20, dw_last / 3.0);
+        else dw *= (dw_last == 0.0 ? 100.0 : 8.0);
+        if (++tries > 40 || dw > 1e20) numerical = true;
+        STI(SI_NREG) += 1;
+      }
+      const int passes_used = failed ? STI(SI_SWEEPS) : 0;
+      const bool again = failed && !numerical && sweep + 1 < max_sweeps && passes_used < o.max_iter;  // (a repeated sweep is a pass)
+      if (again) STI(SI_SWEEPS) = passes_used + 1;
+      if (failed && !again) {  // continue in the next launch (or give up)
+        STI(SI_STEP) = 0;
+        if (numerical) STI(SI_STATUS) = LTOMPC_STATUS_NUMERICAL, STI(SI_DONE) = 1;
+        else STI(SI_RETRY) = 1, STI(SI_TRIES) = tries, STD(ST_DW_TRY) = dw;
+        live = false;
+      }
+      X.delta_w = dw, X.again = again ? 1 : 0, X.live = live ? 1 : 0;
+    }
+    WG_SYNC_LDS();
+    if (!X.again) break;
+  }
+  RTOCK(2);
+  if (w != 0) return;
+  const bool live_f = X.live != 0;  // the sweep succeeded: the step is rolled out
+  if (t == 0 && live_f) {
+    const double delta_w = X.delta_w;
+    STD(ST_DW_LAST) = delta_w > DW_KEEP * psc ? delta_w : 0.0;
+    STD(ST_DW) = delta_w;
+    STI(SI_RETRY) = 0, STI(SI_SKIP_EVAL) = 0;
+    STI(SI_STEP) = 1;
+  }
+  if (!live_f) return;
+  // ---- forward rollout (wavefront 0, as in d_riccati1): lane (g, i) carries dx_i; the full vector is gathered with wave shuffles
+  const bool lane_live = g == 0;
+  double dxi = 0.0, dv[2] = {0.0, 0.0};
+  if (lane_live) PL(W.dX, i, 0, N + 1) = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < N; k++) {
+    FwdRegs fc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) fc.K[j] = S.kk[k * 22 + j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) fc.Kv[j] = S.kk[k * 22 + 16 + j];
+    fc.kff[0] = S.kk[k * 22 + 20], fc.kff[1] = S.kk[k * 22 + 21];
+#pragma unroll
+    for (int j = 0; j < 8; j++) fc.A[j] = S.q[k * QP_NF + QP_A + i * 8 + j];
+    fc.B[0] = S.q[k * QP_NF + QP_B + i * 2], fc.B[1] = S.q[k * QP_NF + QP_B + i * 2 + 1];
+    fc.b = S.q[k * QP_NF + QP_b + i];
+    double dx[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) dx[j] = __shfl(dxi, g + 8 * j);
+    double du[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      double s = fc.kff[c] + fc.Kv[c * 2] * dv[0] + fc.Kv[c * 2 + 1] * dv[1];
+#pragma unroll
+      for (int j = 0; j < 8; j++) s += fc.K[c * 8 + j] * dx[j];
+      du[c] = s;
+    }
+    double s = fc.b + fc.B[0] * du[0] + fc.B[1] * du[1];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s += fc.A[j] * dx[j];
+    dxi = s;
+    dv[0] = du[0], dv[1] = du[1];
+    if (lane_live) {
+      PL(W.dX, i, k + 1, N + 1) = dxi;
+      if (i < 2) PL(W.dU, i, k, N) = du[i];
+    }
+  }
+  RTOCK(3);
+  if (rprof) W.DBG[4] += 1.0;
+#undef RTOCK
+}
+#endif
+
 __global__ void __launch_bounds__(64) k_riccati8(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
   __shared__ RicLds L;
   const int lane = threadIdx.x, g = lane & 7, i = lane >> 3;
   const int jj = blockIdx.x * 8 + g;
   const bool valid = jj < la.nact[0];
   d_riccati8(K, W, L, g, i, la.act[valid ? jj : 0], valid, it_index, max_sweeps);
+}
+
+// Four wavefronts per instance (see d_riccati1q): dynamic LDS ric1q_lds_bytes(N).
+__global__ void __launch_bounds__(256) k_riccati1q(Consts K, Work W, Launch la, int it_index, int max_sweeps) {
+#if defined(LTOMPC_HOST_HARNESS)
+  (void)K, (void)W, (void)la, (void)it_index, (void)max_sweeps;  // (never run by the harness)
+#else
+  extern __shared__ double lds1q[];
+  if ((int)blockIdx.x >= la.nact[0]) return;
+  const int N = W.N;
+  StageLds S{lds1q, lds1q + (size_t)N * QP_NF, lds1q + (size_t)N * (QP_NF + 2)};
+  Ric1qLds& X = *reinterpret_cast<Ric1qLds*>(lds1q + (size_t)N * (QP_NF + 24));
+  d_riccati1q(K, W, X, S, threadIdx.x, la.act[blockIdx.x], it_index, max_sweeps);
+#endif
 }
 
 // One wavefront per instance (narrow launches: once few instances are left, a launch is as long as one wavefront's
