@@ -4,7 +4,7 @@ a sub-batch, a permuted batch."""
 import sys, os, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import ltompc
 T = ltompc.build_tables()
-ENV = ("LTOMPC_RIC1", "LTOMPC_STEP1", "LTOMPC_PACK", "LTOMPC_COMPACT", "LTOMPC_SWEEPS_W")
+ENV = ("LTOMPC_RIC1", "LTOMPC_STEP1", "LTOMPC_PACK", "LTOMPC_COMPACT", "LTOMPC_SWEEPS_W", "LTOMPC_RIC1Q")
 def run(N, B, x0, opts, params, env, ticks=3):
     for k in ENV: os.environ.pop(k, None)
     os.environ.update(env)
@@ -33,7 +33,7 @@ for N, B, opts, params in cases:
     if opts.get("periodic_tables"): x0[: B // 2, 0] += 700.0
     ref = run(N, B, x0, opts, params, {})
     line = f"N={N} B={B} {opts} {params}: statuses tick0 {np.bincount(ref[0][1], minlength=6).tolist()} |"
-    for name, env in (("RIC1=0,STEP1=0", {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}), ("SWEEPS_W=0", {"LTOMPC_SWEEPS_W": "0"}), ("SWEEPS_W=512", {"LTOMPC_SWEEPS_W": "512"}),
+    for name, env in (("RIC1=0,STEP1=0", {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}), ("RIC1Q=0", {"LTOMPC_RIC1Q": "0"}), ("RIC1Q=512", {"LTOMPC_RIC1Q": "512"}), ("SWEEPS_W=0", {"LTOMPC_SWEEPS_W": "0"}), ("SWEEPS_W=512", {"LTOMPC_SWEEPS_W": "512"}),
                       ("COMPACT=0", {"LTOMPC_COMPACT": "0"}), ("PACK=0", {"LTOMPC_PACK": "0"})):
         got = run(N, B, x0, opts, params, env)
         same = all(np.array_equal(got[t][q], ref[t][q]) for t in range(3) for q in range(3))

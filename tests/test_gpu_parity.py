@@ -282,6 +282,14 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     assert np.array_equal(u_nt, u_ref) and np.array_equal(s_nt["iters"][solved], s_ref["iters"][solved])
     monkeypatch.delenv("LTOMPC_RIC1")
     monkeypatch.delenv("LTOMPC_STEP1")
+    # the four-wavefront form of the single-instance sweep (k_riccati1q: default for launches of at most 64 instances) never /
+    # in every launch of the one-instance sweeps: same bits
+    for w in ("0", "512"):
+        monkeypatch.setenv("LTOMPC_RIC1Q", w)
+        u_q, s_q = run()
+        assert np.array_equal(u_q, u_ref) and np.array_equal(s_q["status"], s_ref["status"]), w
+        assert np.array_equal(s_q["iters"], s_ref["iters"]) and np.array_equal(s_q["kkt"][solved], s_ref["kkt"][solved]), w
+    monkeypatch.delenv("LTOMPC_RIC1Q")
     monkeypatch.delenv("LTOMPC_COMPACT")
     # kernels instantiated for the reference's bound pattern vs the run-time pattern ones: same arithmetic, same bits
     monkeypatch.setenv("LTOMPC_BOUNDS", "any")
@@ -316,7 +324,8 @@ def test_iteration_budget_cuts_a_solve_at_the_same_point_on_every_kernel_path(pk
         return out
     ref = run()
     assert (ref[0][1] == 2).sum() >= 1, "the scenario is meant to contain solves that run out of passes"
-    for env in ({"LTOMPC_SWEEPS_W": "0"}, {"LTOMPC_SWEEPS_W": "512"}, {"LTOMPC_RIC1": "0"}, {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}, {"LTOMPC_COMPACT": "0"}):
+    for env in ({"LTOMPC_SWEEPS_W": "0"}, {"LTOMPC_SWEEPS_W": "512"}, {"LTOMPC_RIC1": "0"}, {"LTOMPC_RIC1": "0", "LTOMPC_STEP1": "0"}, {"LTOMPC_COMPACT": "0"},
+                {"LTOMPC_RIC1Q": "0"}, {"LTOMPC_RIC1Q": "512"}, {"LTOMPC_RIC1Q": "512", "LTOMPC_SWEEPS_W": "512"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
