@@ -485,6 +485,8 @@ def main():
         if pmc:
             roofline["traffic"] = pmc.get("traffic_avg_all_launches")
             roofline["traffic_source"] = pmc["source"]
+        if dom == "riccati1":
+            roofline["kernel_note"] = "class riccati1 = k_riccati1 (one wavefront per instance) and k_riccati1q (four, launches of at most 16 instances): both counted"
         # the whole tick against the same roof: every (instance, interval, iteration) moves 3104 algorithmic bytes
         inst_iters = float(np.mean([B_acc + float(a[:max(0, len(a) - 1)].sum()) for a in active_hist])) + extra_inst_iters / args.steps
         tick_bytes = inst_iters * N * BYTES_PER_STAGE_ITER

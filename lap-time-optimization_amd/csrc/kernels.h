@@ -12,7 +12,7 @@
 //                           fraction-to-the-boundary partials
 //   eval8.h       k_eval8 / k_expand8: the same with 8 lanes per (k, b) (latency mode)
 //   riccati.h     k_riccati8 (8 instances per wavefront) / k_riccati1 (one instance per wavefront) / k_riccati1q (one instance
-//                 on four wavefronts, launches of at most 64 instances) / k_riccati (one thread per instance, reference implementation): KKT error, termination, barrier update, Riccati
+//                 on four wavefronts, launches of at most 16 instances) / k_riccati (one thread per instance, reference implementation): KKT error, termination, barrier update, Riccati
 //                 backward sweep with inertia-correcting regularisation, forward rollout
 //   linesearch.h  k_linesearch (filter measures of the step candidates), k_pick (filter test, step length, stall
 //                 bookkeeping), k_update (z += alpha dz), k_step1 (the three fused, one workgroup per instance)

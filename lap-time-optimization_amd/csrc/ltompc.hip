@@ -88,7 +88,8 @@ struct ltompc_solver {
   bool eval8 = true;  // LTOMPC_EVAL=slot: thread-per-slot k_eval / k_expand instead of the wave-cooperative k_eval8 / k_expand8
   int step1_width = 512;  // LTOMPC_STEP1: launches of at most this many instances use the fused step-selection kernel (0 = never)
   int sweeps_width = 16;  // LTOMPC_SWEEPS_W: launches of at most this many instances repeat a failed Riccati sweep inside the launch (up to 4 attempts)
-  int ric1q_width = 64;  // LTOMPC_RIC1Q: launches of at most this many instances use the four-wavefront form of the single-instance sweep (0 = never)
+  int ric1q_width = 16;  // LTOMPC_RIC1Q: launches of at most this many instances use the four-wavefront form of the single-instance sweep (0 = never;
+                         // beside other handles' kernels its 4-wavefront workgroups gain nothing at 64 and lose 1 % at 512, alone it is 7 % faster)
   int ric1_width = 512;  // LTOMPC_RIC1: launches of at most this many instances use the one-wavefront-per-instance sweep (0 = never)
   int last_launches = 0, last_iterations = 0;
 

@@ -282,7 +282,7 @@ def test_compaction_and_serial_riccati_do_not_change_results(pkg, tables, gpu_li
     assert np.array_equal(u_nt, u_ref) and np.array_equal(s_nt["iters"][solved], s_ref["iters"][solved])
     monkeypatch.delenv("LTOMPC_RIC1")
     monkeypatch.delenv("LTOMPC_STEP1")
-    # the four-wavefront form of the single-instance sweep (k_riccati1q: default for launches of at most 64 instances) never /
+    # the four-wavefront form of the single-instance sweep (k_riccati1q: default for launches of at most 16 instances) never /
     # in every launch of the one-instance sweeps: same bits
     for w in ("0", "512"):
         monkeypatch.setenv("LTOMPC_RIC1Q", w)
