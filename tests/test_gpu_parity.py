@@ -911,7 +911,7 @@ def test_node0_rule_on_gpu(pkg, tables, orc, oracle, gpu_lib):
 
 
 def test_split_handles_reproduce_the_single_handle(pkg, tables, gpu_lib):
-    """SplitMPC (bench.py's default on one GPU: the batch as two handles on two streams and host threads, each ticking at its own
+    """SplitMPC (bench.py's default on one GPU: the batch as four handles on their own streams and host threads, each ticking at its own
     pace) returns what one handle returns, bit for bit: controls after every tick, statuses, iteration counts, iterates."""
     import torch
     B, N, K = 1500, 20, 4
