@@ -1,8 +1,8 @@
-"""Per kernel class and launch width: number of launches and average device time, for one warm tick at B = 8192."""
+"""Per kernel class and launch width: number of launches and average device time, for one warm tick.  usage: launch_table.py [ticks] [B]"""
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); import ltompc
 T = ltompc.build_tables()
-B, N = 8192, 40
+B, N = (int(sys.argv[2]) if len(sys.argv) > 2 else 8192), 40
 x0 = ltompc.sample_x0(T, B)
 o = ltompc.default_options()
 m = ltompc.BatchedMPC(T, N, B, options=o); m.set_initial_guess(x0)
@@ -15,7 +15,7 @@ for tick in range(NT):
 kind, width, ms = m.launch_log()
 names = ["eval", "riccati", "expand", "linesearch", "pick", "update", "riccati1", "step1"]
 print(f"tick {dt*1e3:.1f} ms, sum of kernel time {ms.sum():.1f} ms, launches {len(ms)}")
-bins = [(8192, 8192), (2049, 8191), (513, 2048), (65, 512), (9, 64), (1, 8)]
+bins = [(B, B), (B // 2 + 1, B - 1), (513, B // 2), (65, 512), (17, 64), (1, 16)]
 print("kernel       " + "".join(f"{f'{lo}..{hi}':>22s}" for hi, lo in [(b[1], b[0]) for b in bins]))
 for q, nm in enumerate(names):
     row = f"{nm:12s} "
