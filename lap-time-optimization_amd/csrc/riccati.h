@@ -1136,6 +1136,7 @@ __device__ __forceinline__ void d_riccati1(const Consts& K, const Work& W, Ric1L
         if (o_gain || (o_cost && k > 0)) PG(W.RC, ofld, k, RC_NF) = oval;
         if (g <= i && k > 0) PG(W.RC, ofld_p, k, RC_NF) = psym;
       }
+      if (__any(!ok)) break;  // (one instance per wavefront) the sweep has failed - its remaining stages would be thrown away
     }
     // inertia correction schedule per instance (Waechter & Biegler 2006, Algorithm IC)
     const bool failed = live && !ok;
@@ -1501,6 +1502,7 @@ __device__ __forceinline__ void d_riccati1q(const Consts& K, const Work& W, Ric1
         }
       }
       WG_SYNC_LDS();
+      if (!ok) break;  // (uniform: every thread tests the same Huu) the sweep has failed - its remaining stages would be thrown away
     }
     // inertia correction schedule (Waechter & Biegler 2006, Algorithm IC): thread 0 keeps the instance's books
     if (t == 0) {
