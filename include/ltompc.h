@@ -337,6 +337,12 @@ int ltompc_get_history(ltompc_handle h, int* triples, int capacity);
 /* make_step polls the device's count of unfinished instances every n interior-point iterations (default 4). */
 int ltompc_set_poll_every(ltompc_handle h, int n);
 
+/* Launches of at most `width` unfinished instances use the one-instance-per-workgroup kernels (k_riccati1 / k_riccati1q,
+ * k_step1), wider ones the full-width kernels; default 512, 0 = never, at most 512.  Scheduling only: an instance's result does
+ * not depend on it (tests/test_gpu_parity.py).  With several handles ticking beside each other on one GPU a lower switch-over
+ * is faster (their one-instance workgroups queue for the same CUs): four handles of 2048, 128 instead of 512: +2 %. */
+int ltompc_set_narrow_width(ltompc_handle h, int width);
+
 /* Debug hook: raw copy of a device work array in its device layout (see csrc/kernels.h); returns its size in bytes.
  * Work arrays are indexed by the physical slot of an instance; a solve that re-packed its unfinished instances
  * (more than 4 iterations) uses the step buffers as temporaries when it restores the caller's order,

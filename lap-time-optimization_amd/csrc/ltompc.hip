@@ -472,6 +472,13 @@ int ltompc_set_profiling(ltompc_handle h, int on) {
   return 0;
 }
 
+int ltompc_set_narrow_width(ltompc_handle h, int width) {
+  if (!h || width < 0 || width > 512) return fail("ltompc_set_narrow_width: width must be in 0 .. 512");
+  if (h->ric1_width > 0 || width == 0) h->ric1_width = width;  // (stays 0 when the horizon's stage blocks do not fit the LDS)
+  if (h->step1_width > 0 || width == 0) h->step1_width = width;  // (LTOMPC_STEP1=0 / LTOMPC_RIC1=0, the test switches, stay off)
+  return 0;
+}
+
 int ltompc_set_poll_every(ltompc_handle h, int n) {
   if (!h || n < 1) return fail("ltompc_set_poll_every: bad argument");
   h->poll_every = n;

@@ -129,6 +129,10 @@ class BatchedMPC:
     def set_poll_every(self, n: int):
         check(lib().ltompc_set_poll_every(self._h, int(n)))
 
+    def set_narrow_width(self, width: int):
+        """Widest launch (unfinished instances) that uses the one-instance-per-workgroup kernels (default 512); scheduling only."""
+        check(lib().ltompc_set_narrow_width(self._h, int(width)))
+
     def timing(self):
         ms, ln = np.zeros(8), np.zeros(8, dtype=np.int32)
         launches, its = C.c_int(), C.c_int()
@@ -217,7 +221,7 @@ class SplitMPC:
     The device-pointer interface of BatchedMPC for contiguous row blocks: part p owns rows [lo_p, hi_p) of every (B, .) array."""
 
     def __init__(self, tables: TrackTables, n_horizon: int = 10, batch: int = 1, n_parts: int = 4, params: Params | None = None,
-                 options: Options | None = None, device: int = 0):
+                 options: Options | None = None, device: int = 0, narrow_width: int | None = None):
         from concurrent.futures import ThreadPoolExecutor
         self.N, self.B, self.n_parts = int(n_horizon), int(batch), int(n_parts)
         base, rem = divmod(self.B, self.n_parts)
@@ -228,6 +232,13 @@ class SplitMPC:
             self.bounds.append((lo, hi)); lo = hi
         self.parts = [BatchedMPC(tables, n_horizon, hi - lo, params=params, options=options, device=device) for lo, hi in self.bounds]
         self.options, self.params = self.parts[0].options, self.parts[0].params
+        # three or more parts beside each other: their one-instance workgroups queue for the same CUs, so the parts switch to the
+        # one-instance kernels later (ltompc_set_narrow_width; scheduling only, same bits): 128 instead of 512, +2 % with four parts
+        if narrow_width is None and self.n_parts >= 3:
+            narrow_width = 128
+        if narrow_width is not None:
+            for p in self.parts:
+                p.set_narrow_width(narrow_width)
         self._pool = ThreadPoolExecutor(max_workers=self.n_parts)
 
     def close(self):
