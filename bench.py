@@ -103,6 +103,7 @@ def parse_args(argv=None):
     ap.add_argument("--parts", type=int, default=0, help="handles the batch of a GPU is split into, each on its own HIP stream and host thread, ticking at "
                     "its own pace (SplitMPC: one part's narrow tail overlaps the others' full-width launches; results bit-identical to one "
                     "handle).  0 = 4 for a GPU with 4096 instances or more, else 1")
+    ap.add_argument("--narrow-width", type=int, default=-1, help="split handles: widest launch that uses the one-instance kernels (ltompc_set_narrow_width); -1 = SplitMPC's default (128 for three or more parts)")
     ap.add_argument("--total-batch", type=int, default=0, help="strong scaling: this many instances in TOTAL, sharded over the GPUs in contiguous "
                     "blocks (BASELINE config 4: 8192); 0 = weak scaling with --batch instances per GPU")
     ap.add_argument("--horizon", type=int, default=40)
@@ -242,7 +243,8 @@ def main():
     split = n_parts > 1
     stream = torch.cuda.current_stream(dev)
     if split:
-        mpc = ltompc.SplitMPC(tables, n_horizon=N, batch=B, n_parts=n_parts, options=opts, device=local_rank)  # (each part on its own stream)
+        mpc = ltompc.SplitMPC(tables, n_horizon=N, batch=B, n_parts=n_parts, options=opts, device=local_rank,  # (each part on its own stream)
+                              narrow_width=None if args.narrow_width < 0 else args.narrow_width)
     else:
         mpc = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
         mpc.set_stream(stream.cuda_stream)
