@@ -301,7 +301,7 @@ int ltompc_get_recovery(ltompc_handle h, int* n_shift, int* n_fallback, double* 
 /* Profiling: when on, every kernel launch of make_step is bracketed by HIP events on the handle's stream and
  * ltompc_get_timing returns the accumulated device time per kernel class since profiling was switched on:
  * index 0 eval (k_eval or k_eval8), 1 riccati (8 instances per wavefront), 2 expand (k_expand or k_expand8), 3 linesearch,
- * 4 pick, 5 update, 6 riccati1 (the one-wavefront-per-instance sweep of the narrow launches), 7 step1 (their fused
+ * 4 pick, 5 update, 6 riccati1 (the one-instance-per-workgroup sweeps of the narrow launches: k_riccati1, one wavefront, and k_riccati1q, four), 7 step1 (their fused
  * line-search / pick / update kernel).  launches / ip_iterations (iterations launched) refer to the last make_step.
  * Arrays have 8 entries.  Any output may be NULL.
  * on = 0 off, 1 every launch, 2 + c: only the launches of kernel class c (two events per iteration instead of seven:
