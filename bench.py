@@ -609,6 +609,31 @@ def main():
                                                        "achieved": round(by / (t_ms * 1e-3) / 1e9, 1), "frac": round(by / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                 extras[label]["full_width_by_class"] = fwc
             mt.close()
+        def side_run_split(o, label, note):
+            """the headline's handle layout (SplitMPC, n_parts handles ticking at their own pace) with other options"""
+            ms_ = ltompc.SplitMPC(tables, n_horizon=N, batch=B, n_parts=n_parts, options=o, device=local_rank)
+            xt = torch.from_numpy(x0_host).to(dev)
+            xtn, ut = torch.empty_like(xt), torch.zeros(B, 2, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(dev)
+            ms_.set_initial_guess_dev(xt.data_ptr())
+            if args.warmup:
+                ms_.run_ticks(xt.data_ptr(), ut.data_ptr(), xtn.data_ptr(), args.warmup, PLANT_SUBSTEPS)
+                if args.warmup % 2:
+                    xt, xtn = xtn, xt
+            recs = [[None] * args.steps for _ in range(n_parts)]
+            def after_s(pi, t):
+                c, _ = ms_.parts[pi].status_counts()
+                recs[pi][t] = (int(c[0] + c[1]), ms_.parts[pi].timing()["ip_iterations"])
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter()
+            ms_.run_ticks(xt.data_ptr(), ut.data_ptr(), xtn.data_ptr(), args.steps, PLANT_SUBSTEPS, after_tick=after_s)
+            torch.cuda.synchronize(dev)
+            tt = time.perf_counter() - tt
+            c, isum = ms_.status_counts()
+            extras[label] = {"options": note, "converged_solves_per_s": sum(r[0] for q in recs for r in q) / tt, "ms_per_step": 1e3 * tt / args.steps,
+                             "converged_frac_last_tick": float(c[0] + c[1]) / B, "ip_iters_mean_last_tick": isum / B,
+                             "ip_iterations_launched_per_tick": [max(recs[pi][t][1] for pi in range(n_parts)) for t in range(args.steps)]}
+            ms_.close()
         # the same K ticks per instance as a closed-loop ROLLOUT with free-running instances (ltompc_rollout_dev: converged
         # instances start their next tick inside the running batch; bit-identical controls, tests/test_gpu_parity.py)
         mr = ltompc.BatchedMPC(tables, n_horizon=N, batch=B, options=opts, device=local_rank)
@@ -647,6 +672,8 @@ def main():
         # shifted by one interval, barrier restarted at 1e-3 instead of IPOPT's 0.1.  Same NLP, same tolerance.
         to = ltompc.default_options(); to.max_iter, to.warm_shift, to.mu_init_warm = args.max_iter, 1, 1e-3
         side_run(to, "tuned_warm_start", {"warm_shift": 1, "mu_init_warm": 1e-3})
+        if split:  # ... and in the headline's handle layout
+            side_run_split(to, "tuned_warm_start_split", {"warm_shift": 1, "mu_init_warm": 1e-3, "parts": n_parts})
 
     # ---- CPU baseline: the oracle (a port of the same NLP + algorithm) on ALL host cores, on the states, warm starts and
     #      previous controls the GPU handle holds after the timed region (i.e. the tick the GPU would solve next)
