@@ -967,6 +967,36 @@ def test_split_handles_reproduce_the_single_handle(pkg, tables, gpu_lib):
     one.close(); two.close(); three.close()
 
 
+def test_narrow_width_is_scheduling_only(pkg, tables, gpu_lib):
+    """ltompc_set_narrow_width (where a solve switches from the full-width kernels to the one-instance-per-workgroup ones; SplitMPC
+    lowers it for handles that share a GPU): 0 (never), 64, 512 (default) give the same controls, statuses, iteration counts and
+    KKT errors over a cold and two warm ticks; widths outside 0 .. 512 are refused."""
+    N, B = 20, 700
+    x0 = pkg.sample_x0(tables, B, seed=91)
+    def run(width):
+        m = pkg.BatchedMPC(tables, N, B)
+        if width is not None:
+            m.set_narrow_width(width)
+        m.set_initial_guess(x0)
+        x, out = x0.copy(), []
+        for _ in range(3):
+            u = m.make_step(x); st = m.stats()
+            out.append((u.copy(), st["status"].copy(), st["iters"].copy(), st["kkt"].copy()))
+            x = m.plant_step(x, u, 100)
+        m.close()
+        return out
+    ref = run(None)
+    for width in (0, 64, 512):
+        got = run(width)
+        for t in range(3):
+            assert all(np.array_equal(got[t][q], ref[t][q]) for q in range(4)), (width, t)
+    m = pkg.BatchedMPC(tables, N, 8)
+    for bad in (-1, 513):
+        with pytest.raises(pkg.LtompcError):
+            m.set_narrow_width(bad)
+    m.close()
+
+
 def test_eight_shards_of_1024_reproduce_the_8192_batch(pkg, tables, gpu_lib):
     """BASELINE config 4's per-GPU shard: 8 handles of 1024 instances (what 8 ranks hold, lap-time-optimization_amd/sharding.py)
     reproduce the one 8192-instance batch bit for bit over a cold and two warm ticks (controls, statuses, iteration counts)."""
