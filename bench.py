@@ -545,6 +545,24 @@ def main():
         extras["batch1_ms_per_solve"] = 1e3 * t_solve / nb
         extras["batch1_iters_last"] = int(m1.iters[0])
         m1.close()
+        # ... and with the tuned warm start (an option: previous solution shifted by one interval, barrier restarted at 1e-3, safeguarded)
+        ot1 = ltompc.default_options(); ot1.max_iter, ot1.warm_shift, ot1.mu_init_warm = args.max_iter, 1, 1e-3
+        m1 = ltompc.BatchedMPC(tables, n_horizon=N, batch=1, options=ot1, device=local_rank)
+        m1.set_stream(stream.cuda_stream)
+        x1 = ltompc.X0_REFERENCE[None].copy()
+        m1.set_initial_guess(x1)
+        u1 = m1.make_step(x1)
+        x1 = m1.plant_step(x1, u1)
+        torch.cuda.synchronize(dev)
+        t_solve, its1 = 0.0, []
+        for _ in range(nb):
+            tb = time.perf_counter()
+            u1 = m1.make_step(x1)
+            t_solve += time.perf_counter() - tb
+            its1.append(int(m1.iters[0]))
+            x1 = m1.plant_step(x1, u1)
+        extras["batch1_tuned_warm_start"] = {"options": {"warm_shift": 1, "mu_init_warm": 1e-3}, "ms_per_solve": 1e3 * t_solve / nb, "iters": its1}
+        m1.close()
         # BASELINE config 5: closed loop from the reference's x0, horizon N = 60, the reference's hard track constraints,
         # until the horizon reaches the end of the tables (one lap minus the look-ahead)
         o60 = ltompc.default_options()
